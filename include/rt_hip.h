@@ -1,0 +1,171 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X (gfx950) ray-trace imaging backend.
+ *
+ * This is the drop-in boundary for ONE path of the XRayTrace miniapp: the
+ * back-end loop that RayTrace::create_image dispatches to
+ *
+ *     void RayTraceImage<Backend>Loop( int N, const EUV_beam_struct& beam,
+ *         const ray_gain_struct* gain, const ray_seed_struct* seed, int method,
+ *         const std::vector<ray_struct>& rays, double scale, double* image,
+ *         double* I_ang, unsigned int& failure_code,
+ *         std::vector<ray_struct>& failed_rays );
+ *                                   (reference: src/RayTraceImage.cpp:47-75)
+ *
+ * Everything here is plain C: PODs, pointers and sizes.  No C++ types, no
+ * exceptions, no torch types.  The C++ adapter that a reference maintainer
+ * links (raytrace-miniapp_amd/host/RayTraceImageHip.cpp) flattens the
+ * reference structs into these records; tests and bench.py bind the same
+ * symbols through ctypes.  oracle/rt_oracle.c (test infrastructure only)
+ * consumes the same records so that parity tests feed both sides one input.
+ *
+ * All host arrays are borrowed for the duration of a call and never cached
+ * across calls (reference Readme.txt:43).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_N_SUB 3         /* sub-segments per length (RayTraceImageHelper.h:31) */
+#define RT_N_FAILED_MAX 32 /* failed rays reported back (RayTraceImageHelper.h:32) */
+
+/* Status codes returned by every entry point. */
+enum {
+    RT_OK            = 0,
+    RT_ERR_ARG       = 1, /* inconsistent sizes / NULL where data is required   */
+    RT_ERR_NO_DEVICE = 2, /* no usable gfx950 device                           */
+    RT_ERR_HIP       = 3, /* a HIP runtime call failed (see rt_hip_last_error) */
+    RT_ERR_NOMEM     = 4
+};
+
+/* One ray: position (cm) and angle (mrad).  Replaces ray_struct
+ * (src/common/RayTraceImageHelper.h:36-41); same layout, 16 bytes. */
+typedef struct rt_ray {
+    float x, y, a, b;
+} rt_ray;
+
+/* The fields of EUV_beam_struct (src/RayTraceStructures.h:26-52) that the
+ * path reads: the output (deposit) grid and the frequency weights. */
+typedef struct rt_beam {
+    int32_t nx, ny, na, nb, nv;
+    double dx, dy, da, db, dz;
+    const double *x;  /* [nx] */
+    const double *y;  /* [ny] */
+    const double *a;  /* [na] */
+    const double *b;  /* [nb] */
+    const double *dv; /* [nv] */
+} rt_beam;
+
+/* Plasma tables of one length.  Replaces ray_gain_struct
+ * (src/RayTraceStructures.h:218-228).  n,g0,E0: [ix + iy*Nx];
+ * gv: [k + (ix + iy*Nx)*Nv].  gv0 is never read on the path. */
+typedef struct rt_gain {
+    int32_t Nx, Ny, Nv;
+    const double *x; /* [Nx] */
+    const double *y; /* [Ny] */
+    const double *n; /* [Nx*Ny] index of refraction */
+    const float *g0; /* [Nx*Ny] line-centre gain */
+    const float *E0; /* [Nx*Ny] line-centre emissivity, may be NULL */
+    const float *gv; /* [Nx*Ny*Nv] normalised lineshape */
+} rt_gain;
+
+/* Separable seed profile.  Replaces ray_seed_struct
+ * (src/RayTraceStructures.h:276-281). */
+typedef struct rt_seed {
+    int32_t dim[5];
+    const double *x[5];
+    const double *f[5];
+    double f0;
+} rt_seed;
+
+/* Counters measured by the run (not assumed): SURVEY.md 8(d). */
+typedef struct rt_stats {
+    uint64_t n_rays;      /* rays traced                                        */
+    uint64_t cell_steps;  /* iterations of the cell loop, Helper.h:463-504      */
+    uint64_t n_escaped;   /* rays that left the plasma                          */
+    uint64_t n_skipped;   /* rays whose frequency pass was provably all-zero    */
+    float kernel_ms;      /* device time of the trace kernel(s), HIP events     */
+    float total_ms;       /* H2D + kernels + D2H as seen by the host-pointer API*/
+} rt_stats;
+
+/* Number of usable devices; replaces cudaGetDeviceCount in the multi-GPU arm
+ * (src/RayTraceImage.cpp:398-399).  Returns 0 when there is none. */
+int rt_hip_device_count(void);
+
+/* Text of the last HIP failure on this thread ("" if none). */
+const char *rt_hip_last_error(void);
+
+/*
+ * Host-pointer entry point: what RayTraceImageHipLoop calls.
+ * Replaces RayTraceImageCudaLoop (src/RayTraceImageCuda.cu:145-221):
+ * one packed upload, the trace kernel, one download.
+ *   image  [nx*ny*nv], I_ang [na*nb]: overwritten with this call's result
+ *          (create_image hands them over zeroed, RayTraceImage.cpp:271-274).
+ *   failure_code: bit (-error) set for error -1/-2/-3 (Helper.h:47-56,
+ *          RayTraceImageCPU.cpp:32-36); failed_rays receives at most
+ *          max_failed rays, *n_failed the number stored.
+ *   stats may be NULL.
+ */
+int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gain,
+                      const rt_seed *seed, int method, const rt_ray *rays, size_t n_rays,
+                      double scale, double *image, double *I_ang, unsigned int *failure_code,
+                      rt_ray *failed_rays, int max_failed, int *n_failed, rt_stats *stats);
+
+/*
+ * Device-resident plan: the same path with inputs already in HBM, so that a
+ * caller (bench.py, the multi-GPU driver) can time and re-run the kernel and
+ * hand the output buffers to RCCL without a host round trip.
+ */
+typedef struct rt_hip_plan rt_hip_plan;
+
+/* Upload beam grids, gain tables and seed tables in one arena. */
+int rt_hip_plan_create(rt_hip_plan **plan, int device, int N, const rt_beam *beam,
+                       const rt_gain *gain, const rt_seed *seed, int method, double scale);
+
+/* Explicit ray list (the Loop signature's `rays`). */
+int rt_hip_plan_set_rays(rt_hip_plan *plan, const rt_ray *rays, size_t n_rays);
+
+/* Ray list generated on the device from the four 1-D grids exactly as
+ * RayTrace::create_image builds it (src/RayTraceImage.cpp:300-328):
+ * ray t has ijkm = first + t*stride; m = ijkm % nb fastest, then a, y, x;
+ * coordinates are the grids rounded to float.  count rays are generated. */
+int rt_hip_plan_set_ray_grid(rt_hip_plan *plan, const double *gx, int ngx, const double *gy,
+                             int ngy, const double *ga, int nga, const double *gb, int ngb,
+                             int64_t first, int64_t stride, int64_t count);
+
+/* Zero the outputs and run the trace on `stream` (a hipStream_t, may be
+ * NULL = the default stream).  image_dev / iang_dev are device pointers owned
+ * by the caller (e.g. torch tensors) or NULL to use the plan's own buffers.
+ * Asynchronous with respect to the host. */
+int rt_hip_plan_run(rt_hip_plan *plan, void *stream, double *image_dev, double *iang_dev);
+
+/* Wait for the last run; copy results of the plan's own buffers to the host
+ * (either pointer may be NULL), and report failures and counters. */
+int rt_hip_plan_fetch(rt_hip_plan *plan, double *image, double *I_ang,
+                      unsigned int *failure_code, rt_ray *failed_rays, int max_failed,
+                      int *n_failed, rt_stats *stats);
+
+/* Device pointers of the plan's own output buffers (for RCCL / torch views). */
+double *rt_hip_plan_image_ptr(rt_hip_plan *plan);
+double *rt_hip_plan_iang_ptr(rt_hip_plan *plan);
+
+/* Per-ray march record of the last run, for parity tests against the oracle:
+ * gvl/evl [n][L][3] float, ivl [n][L][3] int32, ray2 [n] rt_ray,
+ * flags [n] (bit0 escaped, bit1 error -1, bit2 frequency pass skipped),
+ * steps [n] cell-steps.  Any pointer may be NULL.  Requires
+ * rt_hip_plan_enable_probe(plan, 1) before the run. */
+int rt_hip_plan_enable_probe(rt_hip_plan *plan, int on);
+int rt_hip_plan_fetch_probe(rt_hip_plan *plan, float *gvl, float *evl, int32_t *ivl,
+                            rt_ray *ray2, uint32_t *flags, uint32_t *steps);
+
+void rt_hip_plan_destroy(rt_hip_plan *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */
