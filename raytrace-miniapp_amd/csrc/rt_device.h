@@ -1,0 +1,114 @@
+// rt_device.h -- device-side records of the HIP ray-trace backend (gfx950).
+//
+// Layout in HBM (one arena per plan, packed by rt_hip_plan_create):
+//   per length ii = 1..N-1 (gain[0] is never read on the path except for the
+//   E0 != NULL test, src/common/RayTraceImageHelper.h:402,435-441):
+//     x[Nx], y[Ny]            double   grid coordinates
+//     node[Nx*Ny]             16 B     {double n; float g0; float E0}: the three
+//                                      quantities a cell-step gathers at each of
+//                                      the 4 cell corners (Helper.h:474-489)
+//                                      fused into one record, so a cell-step is
+//                                      two 32-byte reads (corner pairs are adjacent)
+//     gv[Nx*Ny][K]            float    lineshape rows, k fastest (coalesced row read
+//                                      with lanes = frequencies)
+//   beam grids x,y,a,b,dv (double), seed tables (double), the ray list (16 B/ray)
+//   when rays are given explicitly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+namespace rt {
+
+struct alignas(16) Node {
+    double n;
+    float g0;
+    float E0;
+};
+
+struct DevGain {
+    const double *x;
+    const double *y;
+    const Node *node;
+    const float *gv;
+    int Nx, Ny;
+    float lo_x, hi_x, lo_y, hi_y; // plasma box as floats (Helper.h:445-453)
+    int mirror_y;
+    int pad;
+    double inv_hx, inv_hy; // (Nx-1)/(x[Nx-1]-x[0]): index guess for uniform grids
+};
+
+struct DevSeed {
+    const double *x[5];
+    const double *f[5];
+    int dim[5];
+    int pad;
+    double f0;
+};
+
+struct DevBeam {
+    const double *x, *y, *a, *b, *dv;
+    int nx, ny, na, nb, nv;
+    int pad;
+    double dx, dy, da, db;
+};
+
+struct DevRays {
+    const rt_ray *list; // explicit list, or NULL -> generated from the grids
+    const double *gx, *gy, *ga, *gb;
+    int ngx, ngy, nga, ngb;
+    long long first, stride;
+    unsigned long long count;
+};
+
+// Zeroed by a memset node before every run.
+struct DevCtl {
+    unsigned int next_tile;
+    unsigned int failure_code;
+    unsigned int n_failed;
+    unsigned int pad;
+    unsigned long long cell_steps;
+    unsigned long long n_escaped;
+    unsigned long long n_skipped;
+    unsigned long long n_rays;
+    rt_ray failed[RT_N_FAILED_MAX];
+};
+
+struct DevProbe {
+    float *gvl;
+    float *evl;
+    int32_t *ivl;
+    rt_ray *ray2;
+    uint32_t *flags;
+    uint32_t *steps;
+};
+
+struct DevParams {
+    int N, L, K, method;
+    int use_emis, has_seed;
+    float dz0;
+    int probe_on;
+    double scale;
+    DevBeam beam;
+    DevSeed seed;
+    const DevGain *gain; // [N], entry 0 unused
+    DevRays rays;
+    double *image;
+    double *iang;
+    DevCtl *ctl;
+    DevProbe probe;
+    unsigned int n_tiles;
+    unsigned int pad;
+};
+
+// flag bits of the per-ray march record
+enum : unsigned {
+    F_ESCAPED = 1u, // left the plasma (Helper.h:465-469)
+    F_ERR1    = 2u, // error -1, ray ~perpendicular to z (Helper.h:515)
+    F_SKIP    = 4u, // frequency pass provably contributes exactly zero
+    F_VALID   = 8u  // lane holds a ray of this tile
+};
+
+} // namespace rt

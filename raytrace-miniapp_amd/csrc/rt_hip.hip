@@ -1,0 +1,524 @@
+// rt_hip.hip -- the C ABI of include/rt_hip.h on top of the HIP kernel.
+//
+// Replaces the host side of RayTraceImageCudaLoop (src/RayTraceImageCuda.cu:145-221)
+// and of the copy_device helpers (src/RayTraceImageCuda.cu:224-329): where those
+// issue ~30 cudaMalloc/cudaMemcpy calls per create_image, a plan packs every
+// table into ONE arena, uploads it with ONE copy, zeroes outputs + control block
+// and launches ONE kernel.  Nothing is cached across calls (Readme.txt:43).
+#include "rt_kernels.hip"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char *what, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s failed at rt_hip.hip:%d: %s", what, line, hipGetErrorString(e));
+    g_last_error = buf;
+    return RT_ERR_HIP;
+}
+int fail_arg(const char *msg)
+{
+    g_last_error = msg;
+    return RT_ERR_ARG;
+}
+
+#define HIP_TRY(expr)                                \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess)                        \
+            return fail_hip(e_, #expr, __LINE__);    \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over a host staging image of the device arena.
+struct ArenaBuilder {
+    std::vector<unsigned char> host;
+    size_t put(const void *src, size_t bytes)
+    {
+        size_t off = align_up(host.size(), 256);
+        host.resize(off + bytes);
+        if (bytes && src)
+            memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+    size_t reserve(size_t bytes)
+    {
+        size_t off = align_up(host.size(), 256);
+        host.resize(off + bytes);
+        return off;
+    }
+};
+
+} // namespace
+
+struct rt_hip_plan {
+    int device         = 0;
+    int cu_count       = 0;
+    rt::DevParams P    = {};
+    unsigned char *arena = nullptr;
+    size_t arena_bytes = 0;
+    rt_ray *rays_dev   = nullptr;
+    double *grid_dev   = nullptr; // ray grids when rays are generated
+    double *image_own  = nullptr;
+    double *iang_own   = nullptr;
+    rt::DevCtl *ctl    = nullptr;
+    size_t n_image = 0, n_iang = 0;
+    unsigned long long n_rays = 0;
+    // probe
+    bool probe_on        = false;
+    unsigned char *probe = nullptr;
+    size_t probe_rays    = 0;
+    // last run
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t last_stream = nullptr;
+    double *last_image = nullptr, *last_iang = nullptr;
+    bool ran = false;
+    std::chrono::steady_clock::time_point t_created;
+};
+
+extern "C" {
+
+int rt_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *rt_hip_last_error(void) { return g_last_error.c_str(); }
+
+void rt_hip_plan_destroy(rt_hip_plan *p)
+{
+    if (!p)
+        return;
+    (void) hipSetDevice(p->device);
+    if (p->ev0)
+        (void) hipEventDestroy(p->ev0);
+    if (p->ev1)
+        (void) hipEventDestroy(p->ev1);
+    (void) hipFree(p->arena);
+    (void) hipFree(p->rays_dev);
+    (void) hipFree(p->grid_dev);
+    (void) hipFree(p->image_own);
+    (void) hipFree(p->iang_own);
+    (void) hipFree(p->ctl);
+    (void) hipFree(p->probe);
+    delete p;
+}
+
+int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam, const rt_gain *gain,
+                       const rt_seed *seed, int method, double scale)
+{
+    if (!out || !beam || !gain)
+        return fail_arg("rt_hip_plan_create: NULL argument");
+    *out = nullptr;
+    if (N < 2)
+        return fail_arg("rt_hip_plan_create: need at least 2 lengths");
+    if (method != 1 && method != 2)
+        return fail_arg("rt_hip_plan_create: method must be 1 (backward) or 2 (forward)");
+    if (beam->nx < 1 || beam->ny < 1 || beam->na < 1 || beam->nb < 1 || beam->nv < 1)
+        return fail_arg("rt_hip_plan_create: empty beam grid");
+    const int L = N - 1;
+    const size_t per_wave_lds = (size_t) L * RT_N_SUB * rt::WAVE * 12;
+    if (per_wave_lds > 64 * 1024)
+        return fail_arg("rt_hip_plan_create: too many lengths for the LDS record slab");
+    const int K = beam->nv;
+    for (int i = 1; i < N; i++) {
+        if (gain[i].Nx < 2 || gain[i].Ny < 2 || !gain[i].x || !gain[i].y || !gain[i].n || !gain[i].g0 ||
+            !gain[i].gv)
+            return fail_arg("rt_hip_plan_create: incomplete gain table");
+        if (gain[i].Nv != K)
+            return fail_arg("rt_hip_plan_create: gain.Nv != beam.nv");
+    }
+    int ndev = rt_hip_device_count();
+    if (ndev <= 0) {
+        g_last_error = "no HIP device";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev)
+        return fail_arg("rt_hip_plan_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+
+    rt_hip_plan *p = new rt_hip_plan();
+    p->t_created   = std::chrono::steady_clock::now();
+    p->device      = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete p;
+        return fail_hip(e, "hipGetDeviceProperties", __LINE__);
+    }
+    p->cu_count = prop.multiProcessorCount;
+
+    // ---- pack the arena -------------------------------------------------
+    ArenaBuilder ab;
+    std::vector<rt::DevGain> dg((size_t) N);
+    struct GOff {
+        size_t x, y, node, gv;
+    };
+    std::vector<GOff> goff((size_t) N);
+    const bool use_emis = gain[0].E0 != nullptr && seed == nullptr; // Helper.h:402
+    for (int i = 1; i < N; i++) {
+        const rt_gain &g  = gain[i];
+        const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
+        goff[i].x         = ab.put(g.x, sizeof(double) * (size_t) g.Nx);
+        goff[i].y         = ab.put(g.y, sizeof(double) * (size_t) g.Ny);
+        goff[i].node      = ab.reserve(sizeof(rt::Node) * npix);
+        rt::Node *nd      = reinterpret_cast<rt::Node *>(ab.host.data() + goff[i].node);
+        for (size_t c = 0; c < npix; c++) {
+            nd[c].n  = g.n[c];
+            nd[c].g0 = g.g0[c];
+            nd[c].E0 = g.E0 ? g.E0[c] : 0.0f;
+        }
+        goff[i].gv = ab.put(g.gv, sizeof(float) * npix * (size_t) K);
+        rt::DevGain &d = dg[(size_t) i];
+        d.Nx           = g.Nx;
+        d.Ny           = g.Ny;
+        d.lo_x         = (float) g.x[0];
+        d.hi_x         = (float) g.x[g.Nx - 1];
+        d.lo_y         = (float) g.y[0];
+        d.hi_y         = (float) g.y[g.Ny - 1];
+        d.mirror_y     = 0;
+        if (d.lo_y >= 0) { // Helper.h:449-453
+            d.lo_y     = -d.hi_y;
+            d.mirror_y = 1;
+        }
+        d.inv_hx = (double) (g.Nx - 1) / (g.x[g.Nx - 1] - g.x[0]);
+        d.inv_hy = (double) (g.Ny - 1) / (g.y[g.Ny - 1] - g.y[0]);
+        if (!std::isfinite(d.inv_hx))
+            d.inv_hx = 0.0;
+        if (!std::isfinite(d.inv_hy))
+            d.inv_hy = 0.0;
+    }
+    const size_t off_bx  = ab.put(beam->x, sizeof(double) * (size_t) beam->nx);
+    const size_t off_by  = ab.put(beam->y, sizeof(double) * (size_t) beam->ny);
+    const size_t off_ba  = ab.put(beam->a, sizeof(double) * (size_t) beam->na);
+    const size_t off_bb  = ab.put(beam->b, sizeof(double) * (size_t) beam->nb);
+    const size_t off_bdv = ab.put(beam->dv, sizeof(double) * (size_t) beam->nv);
+    size_t off_sx[5] = { 0 }, off_sf[5] = { 0 };
+    if (seed) {
+        for (int i = 0; i < 5; i++) {
+            if (seed->dim[i] < 2 || !seed->x[i] || !seed->f[i]) {
+                delete p;
+                return fail_arg("rt_hip_plan_create: incomplete seed table");
+            }
+            off_sx[i] = ab.put(seed->x[i], sizeof(double) * (size_t) seed->dim[i]);
+            off_sf[i] = ab.put(seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
+        }
+        if (seed->dim[4] != K) {
+            delete p;
+            return fail_arg("rt_hip_plan_create: seed.dim[4] != beam.nv");
+        }
+    }
+    const size_t off_gain = ab.reserve(sizeof(rt::DevGain) * (size_t) N);
+
+#define PLAN_TRY(expr)                                   \
+    do {                                                 \
+        hipError_t e_ = (expr);                          \
+        if (e_ != hipSuccess) {                          \
+            rt_hip_plan_destroy(p);                      \
+            return fail_hip(e_, #expr, __LINE__);        \
+        }                                                \
+    } while (0)
+
+    p->arena_bytes = align_up(ab.host.size(), 256);
+    PLAN_TRY(hipMalloc((void **) &p->arena, p->arena_bytes));
+    unsigned char *A = p->arena;
+    for (int i = 1; i < N; i++) {
+        dg[(size_t) i].x    = reinterpret_cast<const double *>(A + goff[i].x);
+        dg[(size_t) i].y    = reinterpret_cast<const double *>(A + goff[i].y);
+        dg[(size_t) i].node = reinterpret_cast<const rt::Node *>(A + goff[i].node);
+        dg[(size_t) i].gv   = reinterpret_cast<const float *>(A + goff[i].gv);
+    }
+    memcpy(ab.host.data() + off_gain, dg.data(), sizeof(rt::DevGain) * (size_t) N);
+    PLAN_TRY(hipMemcpy(p->arena, ab.host.data(), ab.host.size(), hipMemcpyHostToDevice));
+
+    rt::DevParams &P = p->P;
+    P.N        = N;
+    P.L        = L;
+    P.K        = K;
+    P.method   = method;
+    P.use_emis = use_emis ? 1 : 0;
+    P.has_seed = seed ? 1 : 0;
+    P.dz0      = (float) beam->dz; // RayTraceImageCPU.cpp:31: double -> float at the call
+    P.scale    = scale;
+    P.beam.x   = reinterpret_cast<const double *>(A + off_bx);
+    P.beam.y   = reinterpret_cast<const double *>(A + off_by);
+    P.beam.a   = reinterpret_cast<const double *>(A + off_ba);
+    P.beam.b   = reinterpret_cast<const double *>(A + off_bb);
+    P.beam.dv  = reinterpret_cast<const double *>(A + off_bdv);
+    P.beam.nx  = beam->nx;
+    P.beam.ny  = beam->ny;
+    P.beam.na  = beam->na;
+    P.beam.nb  = beam->nb;
+    P.beam.nv  = beam->nv;
+    P.beam.dx  = beam->dx;
+    P.beam.dy  = beam->dy;
+    P.beam.da  = beam->da;
+    P.beam.db  = beam->db;
+    if (seed) {
+        for (int i = 0; i < 5; i++) {
+            P.seed.x[i]   = reinterpret_cast<const double *>(A + off_sx[i]);
+            P.seed.f[i]   = reinterpret_cast<const double *>(A + off_sf[i]);
+            P.seed.dim[i] = seed->dim[i];
+        }
+        P.seed.f0 = seed->f0;
+    }
+    P.gain = reinterpret_cast<const rt::DevGain *>(A + off_gain);
+
+    p->n_image = (size_t) beam->nx * (size_t) beam->ny * (size_t) beam->nv;
+    p->n_iang  = (size_t) beam->na * (size_t) beam->nb;
+    PLAN_TRY(hipMalloc((void **) &p->ctl, sizeof(rt::DevCtl)));
+    PLAN_TRY(hipEventCreate(&p->ev0));
+    PLAN_TRY(hipEventCreate(&p->ev1));
+    P.ctl = p->ctl;
+    *out  = p;
+    return RT_OK;
+}
+
+int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
+{
+    if (!p || (n_rays && !rays))
+        return fail_arg("rt_hip_plan_set_rays: NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    (void) hipFree(p->rays_dev);
+    p->rays_dev = nullptr;
+    if (n_rays) {
+        HIP_TRY(hipMalloc((void **) &p->rays_dev, n_rays * sizeof(rt_ray)));
+        HIP_TRY(hipMemcpy(p->rays_dev, rays, n_rays * sizeof(rt_ray), hipMemcpyHostToDevice));
+    }
+    p->P.rays       = {};
+    p->P.rays.list  = p->rays_dev;
+    p->P.rays.count = n_rays;
+    p->n_rays       = n_rays;
+    return RT_OK;
+}
+
+int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const double *gy, int ngy,
+                             const double *ga, int nga, const double *gb, int ngb, int64_t first,
+                             int64_t stride, int64_t count)
+{
+    if (!p || !gx || !gy || !ga || !gb || ngx < 1 || ngy < 1 || nga < 1 || ngb < 1)
+        return fail_arg("rt_hip_plan_set_ray_grid: bad grid");
+    const int64_t total = (int64_t) ngx * ngy * nga * ngb;
+    if (total > 0x7fffffffLL) // the reference indexes rays with int (RayTraceImage.cpp:302)
+        return fail_arg("rt_hip_plan_set_ray_grid: more than 2^31 rays");
+    if (first < 0 || stride < 1 || count < 0 || (count > 0 && first + (count - 1) * stride >= total))
+        return fail_arg("rt_hip_plan_set_ray_grid: ray range outside the grid");
+    HIP_TRY(hipSetDevice(p->device));
+    (void) hipFree(p->grid_dev);
+    p->grid_dev     = nullptr;
+    const size_t nn = (size_t) ngx + (size_t) ngy + (size_t) nga + (size_t) ngb;
+    std::vector<double> h(nn);
+    memcpy(h.data(), gx, sizeof(double) * (size_t) ngx);
+    memcpy(h.data() + ngx, gy, sizeof(double) * (size_t) ngy);
+    memcpy(h.data() + ngx + ngy, ga, sizeof(double) * (size_t) nga);
+    memcpy(h.data() + ngx + ngy + nga, gb, sizeof(double) * (size_t) ngb);
+    HIP_TRY(hipMalloc((void **) &p->grid_dev, nn * sizeof(double)));
+    HIP_TRY(hipMemcpy(p->grid_dev, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    rt::DevRays &R = p->P.rays;
+    R              = {};
+    R.list         = nullptr;
+    R.gx           = p->grid_dev;
+    R.gy           = p->grid_dev + ngx;
+    R.ga           = p->grid_dev + ngx + ngy;
+    R.gb           = p->grid_dev + ngx + ngy + nga;
+    R.ngx          = ngx;
+    R.ngy          = ngy;
+    R.nga          = nga;
+    R.ngb          = ngb;
+    R.first        = first;
+    R.stride       = stride;
+    R.count        = (unsigned long long) count;
+    p->n_rays      = (unsigned long long) count;
+    return RT_OK;
+}
+
+int rt_hip_plan_enable_probe(rt_hip_plan *p, int on)
+{
+    if (!p)
+        return fail_arg("rt_hip_plan_enable_probe: NULL plan");
+    p->probe_on = on != 0;
+    return RT_OK;
+}
+
+static int plan_prepare_probe(rt_hip_plan *p)
+{
+    const size_t n = (size_t) p->n_rays;
+    const size_t S = (size_t) p->P.L * RT_N_SUB;
+    if (!p->probe_on) {
+        p->P.probe_on = 0;
+        return RT_OK;
+    }
+    if (p->probe_rays != n || !p->probe) {
+        (void) hipFree(p->probe);
+        p->probe = nullptr;
+        size_t bytes = n * S * 12 + n * (sizeof(rt_ray) + 8) + 1024;
+        HIP_TRY(hipMalloc((void **) &p->probe, bytes));
+        p->probe_rays = n;
+    }
+    unsigned char *b = p->probe;
+    p->P.probe.gvl   = reinterpret_cast<float *>(b);
+    b += n * S * 4;
+    p->P.probe.evl = reinterpret_cast<float *>(b);
+    b += n * S * 4;
+    p->P.probe.ivl = reinterpret_cast<int32_t *>(b);
+    b += n * S * 4;
+    p->P.probe.ray2 = reinterpret_cast<rt_ray *>(b);
+    b += n * sizeof(rt_ray);
+    p->P.probe.flags = reinterpret_cast<uint32_t *>(b);
+    b += n * 4;
+    p->P.probe.steps = reinterpret_cast<uint32_t *>(b);
+    p->P.probe_on    = 1;
+    return RT_OK;
+}
+
+int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *iang_dev)
+{
+    if (!p)
+        return fail_arg("rt_hip_plan_run: NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (!image_dev) {
+        if (!p->image_own)
+            HIP_TRY(hipMalloc((void **) &p->image_own, p->n_image * sizeof(double)));
+        image_dev = p->image_own;
+    }
+    if (!iang_dev) {
+        if (!p->iang_own)
+            HIP_TRY(hipMalloc((void **) &p->iang_own, p->n_iang * sizeof(double)));
+        iang_dev = p->iang_own;
+    }
+    int rc = plan_prepare_probe(p);
+    if (rc != RT_OK)
+        return rc;
+    if (p->probe_on && p->n_rays)
+        HIP_TRY(hipMemsetAsync(p->probe, 0, (size_t) p->n_rays * ((size_t) p->P.L * RT_N_SUB * 12 + sizeof(rt_ray) + 8), stream));
+    HIP_TRY(hipMemsetAsync(image_dev, 0, p->n_image * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(iang_dev, 0, p->n_iang * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(p->ctl, 0, sizeof(rt::DevCtl), stream));
+    p->P.image   = image_dev;
+    p->P.iang    = iang_dev;
+    p->P.n_tiles = (unsigned) ((p->n_rays + rt::WAVE - 1) / rt::WAVE);
+
+    // launch geometry: persistent waves, 1..4 waves per workgroup by LDS slab size
+    const size_t per_wave_lds = (size_t) p->P.L * RT_N_SUB * rt::WAVE * 12;
+    int waves                 = (int) ((48 * 1024) / per_wave_lds);
+    waves                     = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+    const int block           = waves * rt::WAVE;
+    const size_t lds_bytes    = per_wave_lds * (size_t) waves;
+    int per_cu                = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_trace_kernel, block, lds_bytes));
+    if (per_cu < 1)
+        per_cu = 1;
+    unsigned long long want = ((unsigned long long) p->P.n_tiles + (unsigned) waves - 1) / (unsigned) waves;
+    unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
+    unsigned grid           = (unsigned) (want < cap ? want : cap);
+    HIP_TRY(hipEventRecord(p->ev0, stream));
+    if (grid > 0) {
+        hipLaunchKernelGGL(rt::rt_trace_kernel, dim3(grid), dim3((unsigned) block), lds_bytes, stream, p->P);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(p->ev1, stream));
+    p->last_stream = stream;
+    p->last_image  = image_dev;
+    p->last_iang   = iang_dev;
+    p->ran         = true;
+    return RT_OK;
+}
+
+int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int *failure_code,
+                      rt_ray *failed_rays, int max_failed, int *n_failed, rt_stats *stats)
+{
+    if (!p || !p->ran)
+        return fail_arg("rt_hip_plan_fetch: plan has not run");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->last_stream));
+    if (image)
+        HIP_TRY(hipMemcpy(image, p->last_image, p->n_image * sizeof(double), hipMemcpyDeviceToHost));
+    if (I_ang)
+        HIP_TRY(hipMemcpy(I_ang, p->last_iang, p->n_iang * sizeof(double), hipMemcpyDeviceToHost));
+    rt::DevCtl c;
+    HIP_TRY(hipMemcpy(&c, p->ctl, sizeof(c), hipMemcpyDeviceToHost));
+    if (failure_code)
+        *failure_code = c.failure_code;
+    int nf = (int) (c.n_failed < RT_N_FAILED_MAX ? c.n_failed : RT_N_FAILED_MAX);
+    if (nf > max_failed)
+        nf = max_failed;
+    if (failed_rays)
+        for (int i = 0; i < nf; i++)
+            failed_rays[i] = c.failed[i];
+    if (n_failed)
+        *n_failed = failed_rays ? nf : 0;
+    if (stats) {
+        stats->n_rays     = c.n_rays;
+        stats->cell_steps = c.cell_steps;
+        stats->n_escaped  = c.n_escaped;
+        stats->n_skipped  = c.n_skipped;
+        float ms          = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        stats->kernel_ms = ms;
+        stats->total_ms  = (float) std::chrono::duration<double, std::milli>(
+                              std::chrono::steady_clock::now() - p->t_created).count();
+    }
+    return RT_OK;
+}
+
+double *rt_hip_plan_image_ptr(rt_hip_plan *p) { return p ? p->image_own : nullptr; }
+double *rt_hip_plan_iang_ptr(rt_hip_plan *p) { return p ? p->iang_own : nullptr; }
+
+int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl, rt_ray *ray2,
+                            uint32_t *flags, uint32_t *steps)
+{
+    if (!p || !p->ran || !p->probe_on || !p->probe)
+        return fail_arg("rt_hip_plan_fetch_probe: probe was not enabled for the last run");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->last_stream));
+    const size_t n = (size_t) p->n_rays, S = (size_t) p->P.L * RT_N_SUB;
+    if (gvl)
+        HIP_TRY(hipMemcpy(gvl, p->P.probe.gvl, n * S * 4, hipMemcpyDeviceToHost));
+    if (evl)
+        HIP_TRY(hipMemcpy(evl, p->P.probe.evl, n * S * 4, hipMemcpyDeviceToHost));
+    if (ivl)
+        HIP_TRY(hipMemcpy(ivl, p->P.probe.ivl, n * S * 4, hipMemcpyDeviceToHost));
+    if (ray2)
+        HIP_TRY(hipMemcpy(ray2, p->P.probe.ray2, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
+    if (flags)
+        HIP_TRY(hipMemcpy(flags, p->P.probe.flags, n * 4, hipMemcpyDeviceToHost));
+    if (steps)
+        HIP_TRY(hipMemcpy(steps, p->P.probe.steps, n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gain, const rt_seed *seed,
+                      int method, const rt_ray *rays, size_t n_rays, double scale, double *image,
+                      double *I_ang, unsigned int *failure_code, rt_ray *failed_rays, int max_failed,
+                      int *n_failed, rt_stats *stats)
+{
+    if (!image || !I_ang)
+        return fail_arg("rt_hip_image_loop: NULL output");
+    rt_hip_plan *p = nullptr;
+    int rc         = rt_hip_plan_create(&p, device, N, beam, gain, seed, method, scale);
+    if (rc != RT_OK)
+        return rc;
+    rc = rt_hip_plan_set_rays(p, rays, n_rays);
+    if (rc == RT_OK)
+        rc = rt_hip_plan_run(p, nullptr, nullptr, nullptr);
+    if (rc == RT_OK)
+        rc = rt_hip_plan_fetch(p, image, I_ang, failure_code, failed_rays, max_failed, n_failed, stats);
+    rt_hip_plan_destroy(p);
+    return rc;
+}
+
+} // extern "C"

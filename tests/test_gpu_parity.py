@@ -1,0 +1,76 @@
+"""Parity of the HIP path (through the C ABI) with the reference / oracle.
+
+Tolerances: the march record (gvl, evl, ivl, flags, cell-steps) is integer /
+float32 work reproduced bit for bit; image and I_ang are float64 sums whose
+order differs (atomics, shuffle tree) and whose exp() comes from a different
+libm: gate 1e-5 rel-L2 (BASELINE.json north_star), expected ~1e-14.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+rt = importlib.import_module("raytrace-miniapp_amd")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5          # north_star gate
+TOL_TIGHT = 1e-11   # what f64 reordering + libm differences actually allow
+
+
+def _check_probe(hip_probe, ora):
+    assert np.array_equal(hip_probe["steps"], ora["steps"])
+    assert np.array_equal(hip_probe["flags"] & 3, ora["flags"] & 3)
+    assert np.array_equal(hip_probe["ivl"], ora["ivl"])
+    assert np.array_equal(hip_probe["gvl"].view(np.uint32), ora["gvl"].view(np.uint32))
+    assert np.array_equal(hip_probe["evl"].view(np.uint32), ora["evl"].view(np.uint32))
+
+
+def test_ase_small_image_vs_reference(hip, ase_small, ase_ref):
+    with hip.Plan(ase_small) as plan:
+        out = plan.set_ray_grid().run().fetch()
+    assert out["failure_code"] == 0
+    assert out["stats"]["n_rays"] == 399000
+    assert out["stats"]["cell_steps"] == 4768067          # SURVEY.md 3.3, measured on the reference
+    assert rel_l2(out["image"], ase_ref["image"]) < TOL_TIGHT
+    assert rel_l2(out["I_ang"], ase_ref["I_ang"]) < TOL_TIGHT
+    # the reference harness' own gate against the golden image embedded in the file
+    assert rel_l2(out["image"], ase_small.golden_image) < 5.2e-7
+
+
+def test_ase_small_march_record_bit_exact(hip, oracle, ase_small):
+    ids = np.arange(0, ase_small.n_rays_total, 37, dtype=np.int64)
+    rays = ase_small.build_rays(ids)
+    with hip.Plan(ase_small) as plan:
+        plan.set_rays(rays).enable_probe().run()
+        out = plan.fetch()
+        pr = plan.fetch_probe()
+    ora = oracle.probe(ase_small, rays, want_Iv=False)
+    _check_probe(pr, ora)
+    ok = ora["err"] == 0
+    assert np.array_equal(pr["ray2"]["x"][ok], ora["ray2"]["x"][ok])
+    assert np.array_equal(pr["ray2"]["y"][ok], ora["ray2"]["y"][ok])
+    assert out["failure_code"] == 0
+
+
+def test_seed_small_image_vs_reference(hip, seed_small, seed_ref):
+    with hip.Plan(seed_small) as plan:
+        out = plan.set_ray_grid().run().fetch()
+    assert out["failure_code"] == 0
+    assert out["stats"]["n_rays"] == 7803000
+    assert out["stats"]["cell_steps"] == 53573880
+    assert rel_l2(out["image"], seed_ref["image"]) < TOL
+    assert rel_l2(out["I_ang"], seed_ref["I_ang"]) < TOL
+    assert rel_l2(out["image"], seed_small.golden_image) < 5.2e-7
+
+
+def test_seed_small_march_record_bit_exact(hip, oracle, seed_small):
+    ids = np.arange(0, seed_small.n_rays_total, 1009, dtype=np.int64)
+    rays = seed_small.build_rays(ids)
+    with hip.Plan(seed_small) as plan:
+        plan.set_rays(rays).enable_probe().run()
+        plan.fetch()
+        pr = plan.fetch_probe()
+    ora = oracle.probe(seed_small, rays, want_Iv=False)
+    _check_probe(pr, ora)
