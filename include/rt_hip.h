@@ -150,6 +150,10 @@ int rt_hip_plan_fetch(rt_hip_plan *plan, double *image, double *I_ang,
                       unsigned int *failure_code, rt_ray *failed_rays, int max_failed,
                       int *n_failed, rt_stats *stats);
 
+/* Device time in ms of the trace kernel of the last run (HIP events recorded on
+ * the run's stream around the launch).  Waits for that run to finish. */
+int rt_hip_plan_kernel_ms(rt_hip_plan *plan, float *ms);
+
 /* Device pointers of the plan's own output buffers (for RCCL / torch views). */
 double *rt_hip_plan_image_ptr(rt_hip_plan *plan);
 double *rt_hip_plan_iang_ptr(rt_hip_plan *plan);

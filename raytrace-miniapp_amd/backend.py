@@ -132,6 +132,12 @@ class Plan:
         return dict(image=image, I_ang=iang, failure_code=code.value, failed_rays=failed[:nf.value].copy(),
                     stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_})
 
+    def kernel_ms(self) -> float:
+        """Device time of the last run's trace kernel (waits for it)."""
+        ms = C.c_float(0)
+        self.hl.check(self.hl.lib.rt_hip_plan_kernel_ms(self._h, C.byref(ms)), "rt_hip_plan_kernel_ms")
+        return float(ms.value)
+
     def fetch_probe(self) -> dict:
         n = self.n_rays
         S = (self.problem.N - 1) * cabi.RT_N_SUB

@@ -475,6 +475,16 @@ int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int
     return RT_OK;
 }
 
+int rt_hip_plan_kernel_ms(rt_hip_plan *p, float *ms)
+{
+    if (!p || !p->ran || !ms)
+        return fail_arg("rt_hip_plan_kernel_ms: plan has not run");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return RT_OK;
+}
+
 double *rt_hip_plan_image_ptr(rt_hip_plan *p) { return p ? p->image_own : nullptr; }
 double *rt_hip_plan_iang_ptr(rt_hip_plan *p) { return p ? p->iang_own : nullptr; }
 
