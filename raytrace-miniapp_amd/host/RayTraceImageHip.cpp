@@ -1,0 +1,144 @@
+// RayTraceImageHip.cpp -- the C++ adapter a reference maintainer adds next to
+// RayTraceImageCPU.cpp / RayTraceImageCuda.cu.  It implements the back-end loop
+// signature that RayTrace::create_image dispatches to (declared `extern` at
+// src/RayTraceImage.cpp:47-75) by flattening the reference structs into the
+// POD records of include/rt_hip.h and calling the C ABI of librt_hip.so.
+//
+// Compiled against the reference's own headers (-I<reference>/src
+// -I<reference>/src/include) -- nothing of the reference is restated here.
+// See INTEGRATION.md for the dispatcher / harness / CMake lines that go with it.
+//
+//   RayTraceImageHipLoop          one device ("hip" arm)
+//   RayTraceImageHipMultiGPULoop  all devices of the node ("hip-multigpu" arm):
+//        contiguous ray chunks like RayTraceImageThreadLoop
+//        (src/RayTraceImage.cpp:89-134), but each worker binds its own device
+//        (the reference calls setGPU in the spawning thread, :116, so its
+//        workers never inherit the device).
+#include "RayTrace.h"
+#include "common/RayTraceImageHelper.h"
+#include "utilities/RayUtilityMacros.h"
+
+#include "rt_hip.h"
+
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+static_assert(sizeof(ray_struct) == sizeof(rt_ray), "ray_struct and rt_ray must share a layout");
+
+namespace {
+
+struct Flat {
+    rt_beam beam;
+    std::vector<rt_gain> gain;
+    rt_seed seed;
+    bool has_seed;
+};
+
+Flat flatten(int N, const RayTrace::EUV_beam_struct &b, const RayTrace::ray_gain_struct *g,
+             const RayTrace::ray_seed_struct *s)
+{
+    Flat f;
+    f.beam.nx = b.nx; f.beam.ny = b.ny; f.beam.na = b.na; f.beam.nb = b.nb; f.beam.nv = b.nv;
+    f.beam.dx = b.dx; f.beam.dy = b.dy; f.beam.da = b.da; f.beam.db = b.db; f.beam.dz = b.dz;
+    f.beam.x = b.x; f.beam.y = b.y; f.beam.a = b.a; f.beam.b = b.b; f.beam.dv = b.dv;
+    f.gain.resize((size_t) N);
+    for (int i = 0; i < N; i++) {
+        rt_gain &o = f.gain[(size_t) i];
+        o.Nx = g[i].Nx; o.Ny = g[i].Ny; o.Nv = g[i].Nv;
+        o.x = g[i].x; o.y = g[i].y; o.n = g[i].n;
+        o.g0 = g[i].g0; o.E0 = g[i].E0; o.gv = g[i].gv;
+    }
+    f.has_seed = s != NULL;
+    memset(&f.seed, 0, sizeof(f.seed));
+    if (s) {
+        for (int i = 0; i < 5; i++) {
+            f.seed.dim[i] = s->dim[i];
+            f.seed.x[i]   = s->x[i];
+            f.seed.f[i]   = s->f[i];
+        }
+        f.seed.f0 = s->f0;
+    }
+    return f;
+}
+
+void run_on_device(int device, int N, const Flat &f, int method, const ray_struct *rays, size_t n_rays,
+                   double scale, double *image, double *I_ang, unsigned int &failure_code,
+                   std::vector<ray_struct> &failed_rays, std::string &error)
+{
+    rt_ray failed[RT_N_FAILED_MAX];
+    int n_failed      = 0;
+    unsigned int code = 0;
+    int rc = rt_hip_image_loop(device, N, &f.beam, f.gain.data(), f.has_seed ? &f.seed : NULL, method,
+                               reinterpret_cast<const rt_ray *>(rays), n_rays, scale, image, I_ang, &code,
+                               failed, RT_N_FAILED_MAX, &n_failed, NULL);
+    if (rc != RT_OK) {
+        error = std::string("HIP backend error: ") + rt_hip_last_error();
+        return;
+    }
+    failure_code |= code;
+    for (int i = 0; i < n_failed; i++) {
+        ray_struct r;
+        memcpy(&r, &failed[i], sizeof(r));
+        failed_rays.push_back(r);
+    }
+}
+
+} // namespace
+
+int RayTraceImageHipDeviceCount() { return rt_hip_device_count(); }
+
+void RayTraceImageHipLoop(int N, const RayTrace::EUV_beam_struct &beam, const RayTrace::ray_gain_struct *gain,
+    const RayTrace::ray_seed_struct *seed, int method, const std::vector<ray_struct> &rays, double scale,
+    double *image, double *I_ang, unsigned int &failure_code, std::vector<ray_struct> &failed_rays)
+{
+    failure_code = 0;
+    Flat f       = flatten(N, beam, gain, seed);
+    std::string error;
+    run_on_device(0, N, f, method, rays.empty() ? NULL : &rays[0], rays.size(), scale, image, I_ang,
+                  failure_code, failed_rays, error);
+    if (!error.empty())
+        RAY_ERROR(error); // device/runtime errors end the process, as CUDA_CHECK does (RayTraceImageCuda.cu:8-18)
+}
+
+void RayTraceImageHipMultiGPULoop(int N, const RayTrace::EUV_beam_struct &beam,
+    const RayTrace::ray_gain_struct *gain, const RayTrace::ray_seed_struct *seed, int method,
+    const std::vector<ray_struct> &rays, double scale, double *image, double *I_ang,
+    unsigned int &failure_code, std::vector<ray_struct> &failed_rays)
+{
+    failure_code   = 0;
+    const int ndev = rt_hip_device_count();
+    if (ndev < 1)
+        RAY_ERROR("Hip-MultiGPU is not availible");
+    Flat f             = flatten(N, beam, gain, seed);
+    const size_t n_img = (size_t) beam.nx * beam.ny * beam.nv;
+    const size_t n_ang = (size_t) beam.na * beam.nb;
+    const size_t chunk = rays.size() / (size_t) ndev + 1;
+    std::vector<std::vector<double>> img((size_t) ndev), ang((size_t) ndev);
+    std::vector<unsigned int> code((size_t) ndev, 0);
+    std::vector<std::vector<ray_struct>> failed((size_t) ndev);
+    std::vector<std::string> error((size_t) ndev);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndev; d++) {
+        const size_t begin = std::min((size_t) d * chunk, rays.size());
+        const size_t count = std::min(chunk, rays.size() - begin);
+        img[(size_t) d].assign(n_img, 0.0);
+        ang[(size_t) d].assign(n_ang, 0.0);
+        workers.push_back(std::thread([&, d, begin, count]() {
+            run_on_device(d, N, f, method, count ? &rays[begin] : NULL, count, scale, img[(size_t) d].data(),
+                          ang[(size_t) d].data(), code[(size_t) d], failed[(size_t) d], error[(size_t) d]);
+        }));
+    }
+    for (int d = 0; d < ndev; d++) {
+        workers[(size_t) d].join();
+        if (!error[(size_t) d].empty())
+            RAY_ERROR(error[(size_t) d]);
+        for (size_t j = 0; j < n_img; j++)
+            image[j] += img[(size_t) d][j];
+        for (size_t j = 0; j < n_ang; j++)
+            I_ang[j] += ang[(size_t) d][j];
+        failure_code |= code[(size_t) d];
+        failed_rays.insert(failed_rays.end(), failed[(size_t) d].begin(), failed[(size_t) d].end());
+    }
+}
