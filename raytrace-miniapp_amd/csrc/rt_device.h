@@ -100,7 +100,7 @@ struct DevParams {
     DevCtl *ctl;
     DevProbe probe;
     unsigned int n_tiles;
-    unsigned int pad;
+    unsigned int debug; // bit0: skip phase B (profiling only, RT_HIP_DEBUG env)
 };
 
 // flag bits of the per-ray march record

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -276,6 +277,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         P.seed.f0 = seed->f0;
     }
     P.gain = reinterpret_cast<const rt::DevGain *>(A + off_gain);
+    if (const char *dbg = getenv("RT_HIP_DEBUG"))
+        P.debug = (unsigned) strtoul(dbg, nullptr, 0);
 
     p->n_image = (size_t) beam->nx * (size_t) beam->ny * (size_t) beam->nv;
     p->n_iang  = (size_t) beam->na * (size_t) beam->nb;
@@ -484,6 +487,18 @@ int rt_hip_plan_kernel_ms(rt_hip_plan *p, float *ms)
     HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
     return RT_OK;
 }
+
+#ifdef RT_INSTRUMENT
+// diagnostic build only: read and clear the loop-occupancy counters
+int rt_hip_debug_counters(unsigned long long *out8)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_inst), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = { 0 };
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_inst), z, sizeof(z)));
+    return RT_OK;
+}
+#endif
 
 double *rt_hip_plan_image_ptr(rt_hip_plan *p) { return p ? p->image_own : nullptr; }
 double *rt_hip_plan_iang_ptr(rt_hip_plan *p) { return p ? p->iang_own : nullptr; }

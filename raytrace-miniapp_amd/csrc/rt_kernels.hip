@@ -27,6 +27,30 @@ namespace rt {
 
 constexpr int WAVE = 64;
 
+#ifdef RT_INSTRUMENT
+// Diagnostic build only (make instrument): lane-occupancy of the three nested
+// march loops.  g_inst[2i] = wave-level iterations, g_inst[2i+1] = active-lane
+// iterations, i = 0 inner (Helper.h:279), 1 cross (:326), 2 cell (:463).
+__device__ unsigned long long g_inst[8];
+struct Inst {
+    unsigned w[3] = { 0, 0, 0 }, a[3] = { 0, 0, 0 };
+    __device__ __forceinline__ void tick(int i)
+    {
+        a[i]++;
+        unsigned long long m = __ballot(1);
+        if ((int) (threadIdx.x & 63) == __ffsll((long long) m) - 1)
+            w[i]++;
+    }
+};
+#define RT_TICK(i) inst.tick(i)
+#define RT_INST_ARG , Inst &inst
+#define RT_INST_PASS , inst
+#else
+#define RT_TICK(i)
+#define RT_INST_ARG
+#define RT_INST_PASS
+#endif
+
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & (WAVE - 1)); }
 
@@ -143,7 +167,7 @@ __device__ __forceinline__ int deposit_index(int n, const double *g, double d, d
 // Helper.h:270-313
 __device__ __forceinline__ float step_linear_medium(float &rx, float &ry, float &rz, float &sx, float &sy,
                                                     float &sz, float n0, float gx, float gy, float lim0,
-                                                    float lim1, float lim2)
+                                                    float lim1, float lim2 RT_INST_ARG)
 {
     const float c = 0.5f;
     float path    = 0.0f;
@@ -177,6 +201,7 @@ __device__ __forceinline__ float step_linear_medium(float &rx, float &ry, float 
         sz += c2 * fz;
         renormalise(sx, sy, sz);
         path += h;
+        RT_TICK(0);
     }
     return path;
 }
@@ -185,7 +210,7 @@ __device__ __forceinline__ float step_linear_medium(float &rx, float &ry, float 
 __device__ __forceinline__ float cross_cell(float &px, float &py, float &pz, float &sx, float &sy, float &sz,
                                             float dzrem, double xc0, double xc1, double yc0, double yc1,
                                             float b0, float b1, float b2, float b3, double n00, double n10,
-                                            double n01, double n11, bool mirror_y)
+                                            double n01, double n11, bool mirror_y RT_INST_ARG)
 {
     float z        = 0.0f;
     float path     = 0.0f;
@@ -202,7 +227,8 @@ __device__ __forceinline__ float cross_cell(float &px, float &py, float &pz, flo
         if (mirror_y && py < 0)
             gy = -gy;
         float rx, ry, rz;
-        path += step_linear_medium(rx, ry, rz, sx, sy, sz, n0, gx, gy, 0.1f * wx, 0.1f * wy, dzrem - z);
+        path += step_linear_medium(rx, ry, rz, sx, sy, sz, n0, gx, gy, 0.1f * wx, 0.1f * wy, dzrem - z RT_INST_PASS);
+        RT_TICK(1);
         px += rx;
         py += ry;
         pz += rz;
@@ -332,6 +358,9 @@ rt_trace_kernel(const DevParams P)
         }
         renormalise(sx, sy, sz);
 
+#ifdef RT_INSTRUMENT
+        Inst inst;
+#endif
         bool escaped   = !have; // lanes without a ray never enter the loops
         unsigned steps = 0;
         for (int seg = 0; seg < P.L; seg++) {
@@ -382,7 +411,8 @@ rt_trace_kernel(const DevParams P)
                     if (mirror_y && k2 <= 1)
                         b2 = -b3;
                     float path = cross_cell(px, py, pz, sx, sy, sz, z_stop - z, xc0, xc1, yc0, yc1, b0, b1, b2,
-                                            b3, a00.n, a10.n, a01.n, a11.n, mirror_y);
+                                            b3, a00.n, a10.n, a01.n, a11.n, mirror_y RT_INST_PASS);
+                    RT_TICK(2);
                     z += fabsf(pz);
                     gacc += g0 * path;
                     eacc += E0 * path;
@@ -478,11 +508,22 @@ rt_trace_kernel(const DevParams P)
                 atomicAdd(&P.ctl->n_rays, (unsigned long long) tot_rays);
             }
         }
+#ifdef RT_INSTRUMENT
+        for (int i = 0; i < 3; i++) {
+            unsigned tw = wave_sum_u32(inst.w[i]), ta = wave_sum_u32(inst.a[i]);
+            if (lane == 0) {
+                atomicAdd(&g_inst[2 * i], (unsigned long long) tw);
+                atomicAdd(&g_inst[2 * i + 1], (unsigned long long) ta);
+            }
+        }
+#endif
         // LDS writes of this wave are visible to its own later reads in program order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // ========================= phase B: lanes = frequencies =========================
+        if (P.debug & 1u)
+            continue;
         const unsigned long long any_mask = __ballot((flags & F_VALID) != 0);
         const int n_in_tile               = (int) __popcll(any_mask);
         double angsum                     = 0.0;
