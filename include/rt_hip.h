@@ -91,6 +91,8 @@ typedef struct rt_stats {
     uint64_t n_skipped;   /* rays whose frequency pass was provably all-zero    */
     float kernel_ms;      /* device time of the trace kernel(s), HIP events     */
     float total_ms;       /* H2D + kernels + D2H as seen by the host-pointer API*/
+    float march_ms;       /* device time of the march kernel (rt_march_kernel)  */
+    float freq_ms;        /* device time of the frequency kernel (rt_freq_kernel)*/
 } rt_stats;
 
 /* Number of usable devices; replaces cudaGetDeviceCount in the multi-GPU arm

@@ -60,6 +60,7 @@ class RtStats(C.Structure):
     _fields_ = [
         ("n_rays", C.c_uint64), ("cell_steps", C.c_uint64), ("n_escaped", C.c_uint64),
         ("n_skipped", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float),
+        ("march_ms", C.c_float), ("freq_ms", C.c_float),
     ]
 
 

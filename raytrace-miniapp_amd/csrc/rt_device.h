@@ -57,18 +57,31 @@ struct DevBeam {
 
 struct DevRays {
     const rt_ray *list; // explicit list, or NULL -> generated from the grids
+    const float *sxy;   // list mode: {tan(1e-3 a), tan(1e-3 b)} per ray (rt_tan_kernel)
     const double *gx, *gy, *ga, *gb;
+    const float *tan_a, *tan_b; // grid mode: tanf(1e-3f * (float) ga[k]), host-computed
     int ngx, ngy, nga, ngb;
     long long first, stride;
     unsigned long long count;
 };
 
+// Per-ray march record, one per ray at rec + ridx * rec_stride (AoS so that a
+// lane that finishes its ray writes one contiguous line):
+//   float gvl[S]; float evl[S]; int ivl[S];          S = (N-1)*3, Helper.h:386-388
+//   float px, py, sx, sy, sz;                        exit position / direction
+//   uint  flags | steps << 8;
+// rec_stride = round16(12 S + 24).
+struct RecMeta {
+    float px, py, sx, sy, sz;
+    unsigned flags_steps;
+};
+
 // Zeroed by a memset node before every run.
 struct DevCtl {
-    unsigned int next_tile;
+    unsigned int next_tile;   // fused kernel: tile counter; march kernel: next ray
+    unsigned int next_tile_b; // frequency kernel: tile counter
     unsigned int failure_code;
     unsigned int n_failed;
-    unsigned int pad;
     unsigned long long cell_steps;
     unsigned long long n_escaped;
     unsigned long long n_skipped;
@@ -101,6 +114,10 @@ struct DevParams {
     DevProbe probe;
     unsigned int n_tiles;
     unsigned int debug; // bit0: skip phase B (profiling only, RT_HIP_DEBUG env)
+    // two-kernel path (rt_march.hip -> records -> rt_freq.hip)
+    unsigned char *rec;
+    unsigned int rec_stride;
+    unsigned int chunk; // rays a wave reserves per fetch of the global ray counter
 };
 
 // flag bits of the per-ray march record

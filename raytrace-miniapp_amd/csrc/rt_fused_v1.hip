@@ -21,285 +21,9 @@
 //            64-lane atomic instruction per tile.
 // Waves pull tiles from one atomic counter (persistent waves): ray cost varies
 // 30x across the image, a static grid would idle on the cheap pixels.
-#include "rt_device.h"
+#include "rt_math.h"
 
 namespace rt {
-
-constexpr int WAVE = 64;
-
-#ifdef RT_INSTRUMENT
-// Diagnostic build only (make instrument): lane-occupancy of the three nested
-// march loops.  g_inst[2i] = wave-level iterations, g_inst[2i+1] = active-lane
-// iterations, i = 0 inner (Helper.h:279), 1 cross (:326), 2 cell (:463).
-__device__ unsigned long long g_inst[8];
-struct Inst {
-    unsigned w[3] = { 0, 0, 0 }, a[3] = { 0, 0, 0 };
-    __device__ __forceinline__ void tick(int i)
-    {
-        a[i]++;
-        unsigned long long m = __ballot(1);
-        if ((int) (threadIdx.x & 63) == __ffsll((long long) m) - 1)
-            w[i]++;
-    }
-};
-#define RT_TICK(i) inst.tick(i)
-#define RT_INST_ARG , Inst &inst
-#define RT_INST_PASS , inst
-#else
-#define RT_TICK(i)
-#define RT_INST_ARG
-#define RT_INST_PASS
-#endif
-
-// ---------------------------------------------------------------- wave helpers
-__device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & (WAVE - 1)); }
-
-__device__ __forceinline__ float sgpr_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
-{
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ double readlane_f64(double v, int l)
-{
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xffffffffu), l);
-    unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), l);
-    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
-}
-
-// ------------------------------------------------------------------ march math
-// Helper.h:73-89.  The reference computes (float)(1.0 / (double)sqrtf(q)).  A
-// correctly rounded float division 1.0f / y gives the same float for every
-// float y (the double-rounded quotient can differ only if 1/y lies within
-// 2^-54 of a 25-bit midpoint, which a 24-bit y cannot produce unless it is a
-// power of two, where both are exact) -- checked exhaustively for y in
-// [0.25, 4) by tests/test_float_identities.py.
-__device__ __forceinline__ void renormalise(float &sx, float &sy, float &sz)
-{
-    float q   = sx * sx + sy * sy + sz * sz;
-    float inv = 1.0f / sqrtf(q);
-    sx *= inv;
-    sy *= inv;
-    sz *= inv;
-}
-
-// Helper.h:153-158
-__device__ __forceinline__ float lerp2(float u, float v, float f00, float f10, float f01, float f11)
-{
-    float u1 = 1.0f - u;
-    float v1 = 1.0f - v;
-    return (u * f10 + u1 * f00) * v1 + (u * f11 + u1 * f01) * v;
-}
-
-// Helper.h:131-143.  The binary search returns the unique u in [1, n-1] with
-// (u == 1 || g[u-1] < v) && (u == n-1 || g[u] >= v) on a non-decreasing grid;
-// we guess u arithmetically (exact for the uniform grids the files hold),
-// repair by at most two neighbour moves and only then fall back to bisection.
-__device__ __forceinline__ uint32_t interval_index(const double *g, uint32_t n, double v, double inv_h)
-{
-    int last = (int) n - 1;
-    int u    = (int) ((v - g[0]) * inv_h) + 1;
-    u        = u < 1 ? 1 : (u > last ? last : u);
-    if (u > 1 && g[u - 1] >= v)
-        --u;
-    if (u > 1 && g[u - 1] >= v)
-        --u;
-    if (u < last && g[u] < v)
-        ++u;
-    if (u < last && g[u] < v)
-        ++u;
-    bool ok = (u == 1 || g[u - 1] < v) && (u == last || g[u] >= v);
-    if (!ok) {
-        uint32_t lo = 0, hi = n - 1;
-        while (hi - lo != 1) {
-            uint32_t mid = (hi + lo) / 2;
-            if (g[mid] >= v)
-                hi = mid;
-            else
-                lo = mid;
-        }
-        u = (int) hi;
-    }
-    return (uint32_t) u;
-}
-
-// Helper.h:101-117
-__device__ __forceinline__ int first_not_below(const double *g, int n, double v)
-{
-    if (v < g[0])
-        return 0;
-    if (v > g[n - 1])
-        return n;
-    int lo = 0, hi = n - 1;
-    while (hi - lo != 1) {
-        int mid = (hi + lo) / 2;
-        if (g[mid] >= v)
-            hi = mid;
-        else
-            lo = mid;
-    }
-    return hi;
-}
-
-// RayTraceImageCPU.cpp:11-16
-__device__ __forceinline__ int deposit_index(int n, const double *g, double d, double v)
-{
-    if (v < g[0] - 0.5 * d || v > g[n - 1] + 0.5 * d)
-        return -1;
-    return first_not_below(g, n, v - 0.5 * d);
-}
-
-// Helper.h:270-313
-__device__ __forceinline__ float step_linear_medium(float &rx, float &ry, float &rz, float &sx, float &sy,
-                                                    float &sz, float n0, float gx, float gy, float lim0,
-                                                    float lim1, float lim2 RT_INST_ARG)
-{
-    const float c = 0.5f;
-    float path    = 0.0f;
-    float dzcap   = c * 1.00001f * lim2;
-    rx = 0.0f;
-    ry = 0.0f;
-    rz = 0.0f;
-    float n = n0;
-    while (fabsf(rx) < lim0 && fabsf(ry) < lim1 && fabsf(rz) < lim2 && (double) fabsf(n - n0) < 0.05) {
-        n        = n0 + rx * gx + ry * gy;
-        float t  = (sx * gx + sy * gy + 1e-12f) / n;
-        float fx = gx / n - sx * t;
-        float fy = gy / n - sy * t;
-        float fz = -sz * t;
-        float h  = c * 0.1f / fabsf(t);
-        h        = h < dzcap ? h : dzcap;
-        float h2 = 1.0001f * (lim2 - fabsf(rz)) / fabsf(sz);
-        float h3 = c * 0.05f * (fabsf(sx) + 5e-4f) / (fabsf(fx) + 1e-8f);
-        float h4 = c * 0.05f * (fabsf(sy) + 5e-4f) / (fabsf(fy) + 1e-8f);
-        h        = h < h2 ? h : h2;
-        h        = h < h3 ? h : h3;
-        h        = h < h4 ? h : h4;
-        float ht = h * t;
-        float c1 = 0.5f * h * h * (1.0f - ht / 3.0f + ht * ht / 12.0f);
-        rx += sx * h + c1 * fx;
-        ry += sy * h + c1 * fy;
-        rz += sz * h + c1 * fz;
-        float c2 = h * (1.0f - 0.5f * ht + ht * ht / 6.0f);
-        sx += c2 * fx;
-        sy += c2 * fy;
-        sz += c2 * fz;
-        renormalise(sx, sy, sz);
-        path += h;
-        RT_TICK(0);
-    }
-    return path;
-}
-
-// Helper.h:318-351
-__device__ __forceinline__ float cross_cell(float &px, float &py, float &pz, float &sx, float &sy, float &sz,
-                                            float dzrem, double xc0, double xc1, double yc0, double yc1,
-                                            float b0, float b1, float b2, float b3, double n00, double n10,
-                                            double n01, double n11, bool mirror_y RT_INST_ARG)
-{
-    float z        = 0.0f;
-    float path     = 0.0f;
-    const float wx = (float) (xc1 - xc0);
-    const float wy = (float) (yc1 - yc0);
-    float ya       = mirror_y ? fabsf(py) : py;
-    while (px > b0 && px < b1 && ya > b2 && ya < b3 && (double) z < 0.999 * (double) dzrem) {
-        ya       = mirror_y ? fabsf(py) : py;
-        float u  = (float) (((double) px - xc0) / (double) wx);
-        float v  = (float) (((double) ya - yc0) / (double) wy);
-        float n0 = lerp2(u, v, (float) n00, (float) n10, (float) n01, (float) n11);
-        float gx = (float) ((1.0 - (double) v) * (n10 - n00) / (double) wx + (double) v * (n11 - n01) / (double) wx);
-        float gy = (float) ((1.0 - (double) u) * (n01 - n00) / (double) wy + (double) u * (n11 - n10) / (double) wy);
-        if (mirror_y && py < 0)
-            gy = -gy;
-        float rx, ry, rz;
-        path += step_linear_medium(rx, ry, rz, sx, sy, sz, n0, gx, gy, 0.1f * wx, 0.1f * wy, dzrem - z RT_INST_PASS);
-        RT_TICK(1);
-        px += rx;
-        py += ry;
-        pz += rz;
-        z += fabsf(rz);
-        ya = mirror_y ? fabsf(py) : py;
-    }
-    return path;
-}
-
-// Helper.h:168-220
-__device__ double pchip_eval(int n, const double *xs, const double *ys, double x)
-{
-    if (x <= xs[0] || n <= 2) {
-        double t = (x - xs[0]) / (xs[1] - xs[0]);
-        return (1.0 - t) * ys[0] + t * ys[1];
-    } else if (x >= xs[n - 1]) {
-        double t = (x - xs[n - 2]) / (xs[n - 1] - xs[n - 2]);
-        return (1.0 - t) * ys[n - 2] + t * ys[n - 1];
-    }
-    int i     = first_not_below(xs, n, x);
-    double fl = ys[i - 1];
-    double fr = ys[i];
-    double t  = (x - xs[i - 1]) / (xs[i] - xs[i - 1]);
-    double gl = 0, gr = 0;
-    if (i <= 1) {
-        gl = fr - fl;
-    } else if ((fl < fr && fl > ys[i - 2]) || (fl > fr && fl < ys[i - 2])) {
-        double fp   = ys[i - 2];
-        double h1   = xs[i - 1] - xs[i - 2];
-        double h2   = xs[i] - xs[i - 1];
-        double w1   = (h2 - h1) / h1;
-        double w2   = h1 / (h1 + h2);
-        gl          = w1 * (fl - fp) + w2 * (fr - fp);
-        double s1   = fabs(fl - fp) / h1;
-        double s2   = fabs(fr - fl) / h2;
-        double gmax = 2 * h2 * (s1 < s2 ? s1 : s2);
-        gl          = ((gl >= 0) ? 1 : -1) * (fabs(gl) < gmax ? fabs(gl) : gmax);
-    }
-    if (i >= n - 1) {
-        gr = fr - fl;
-    } else if ((fr < fl && fr > ys[i + 1]) || (fr > fl && fr < ys[i + 1])) {
-        double fn   = ys[i + 1];
-        double h1   = xs[i] - xs[i - 1];
-        double h2   = xs[i + 1] - xs[i];
-        double w1   = -h2 / (h1 + h2);
-        double w2   = (h2 - h1) / h2;
-        gr          = w1 * (fl - fn) + w2 * (fr - fn);
-        double s1   = fabs(fr - fl) / h1;
-        double s2   = fabs(fn - fr) / h2;
-        double gmax = 2 * h1 * (s1 < s2 ? s1 : s2);
-        gr          = ((gr >= 0) ? 1 : -1) * (fabs(gr) < gmax ? fabs(gr) : gmax);
-    }
-    double t2 = t * t;
-    return fl + t2 * (2 * t - 3) * (fl - fr) + t * gl - t2 * (gl + (1 - t) * (gl + gr));
-}
-
-// Helper.h:230-244: the frequency-independent factor f of the seed profile.
-__device__ double seed_factor(const DevSeed &sd, double x, double y, double a, double b)
-{
-    double f = 0.0;
-    if (x >= sd.x[0][0] && x <= sd.x[0][sd.dim[0] - 1] && y >= sd.x[1][0] && y <= sd.x[1][sd.dim[1] - 1] &&
-        a >= sd.x[2][0] && a <= sd.x[2][sd.dim[2] - 1] && b >= sd.x[3][0] && b <= sd.x[3][sd.dim[3] - 1]) {
-        double fx = pchip_eval(sd.dim[0], sd.x[0], sd.f[0], x);
-        double fy = pchip_eval(sd.dim[1], sd.x[1], sd.f[1], y);
-        double fa = pchip_eval(sd.dim[2], sd.x[2], sd.f[2], a);
-        double fb = pchip_eval(sd.dim[3], sd.x[3], sd.f[3], b);
-        f         = sd.f0 * fx * fy * fa * fb;
-        f         = f < 0.0 ? 0.0 : f;
-    }
-    return f;
-}
 
 // ------------------------------------------------------------------- the kernel
 extern "C" __global__ void __launch_bounds__(256)

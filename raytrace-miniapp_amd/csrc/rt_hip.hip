@@ -5,7 +5,8 @@
 // issue ~30 cudaMalloc/cudaMemcpy calls per create_image, a plan packs every
 // table into ONE arena, uploads it with ONE copy, zeroes outputs + control block
 // and launches ONE kernel.  Nothing is cached across calls (Readme.txt:43).
-#include "rt_kernels.hip"
+#include "rt_freq.hip"      // kernel B (includes rt_march.hip, kernel A)
+#include "rt_fused_v1.hip" // the round-1 fused kernel, kept selectable (RT_HIP_KERNEL=fused)
 
 #include <chrono>
 #include <cmath>
@@ -70,6 +71,11 @@ struct rt_hip_plan {
     size_t arena_bytes = 0;
     rt_ray *rays_dev   = nullptr;
     double *grid_dev   = nullptr; // ray grids when rays are generated
+    float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
+    unsigned char *rec = nullptr; // per-ray march records (two-kernel path)
+    size_t rec_bytes   = 0;
+    bool fused         = false;   // RT_HIP_KERNEL=fused selects the round-1 fused kernel
+    hipEvent_t evm     = nullptr; // between march and frequency kernels
     double *image_own  = nullptr;
     double *iang_own   = nullptr;
     rt::DevCtl *ctl    = nullptr;
@@ -86,6 +92,77 @@ struct rt_hip_plan {
     bool ran = false;
     std::chrono::steady_clock::time_point t_created;
 };
+
+// frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
+// the shipped inputs; 0 = any N), VEC = frequencies per lane per pass
+template <int SF, int VEC>
+static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
+{
+    const size_t ang_bytes = p->n_iang * sizeof(double);
+    const int in_lds       = ang_bytes <= 32 * 1024;
+    const size_t lds       = in_lds ? ang_bytes : 0;
+    int per_cu             = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_freq_kernel<SF, VEC>, 256, lds));
+    if (per_cu < 1)
+        per_cu = 1;
+    unsigned long long want = ((unsigned long long) p->P.n_tiles + 3) / 4;
+    unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
+    if (cap_blocks && cap > cap_blocks)
+        cap = cap_blocks;
+    const unsigned grid = (unsigned) (want < cap ? want : cap);
+    if (grid > 0) {
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, VEC>), dim3(grid), dim3(256), lds, stream, p->P, in_lds);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+// Two-kernel path: march (persistent lanes) -> records in HBM -> frequency pass.
+static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
+{
+    const size_t need = (size_t) p->n_rays * p->P.rec_stride;
+    if (need > p->rec_bytes || !p->rec) {
+        (void) hipFree(p->rec);
+        p->rec = nullptr;
+        HIP_TRY(hipMalloc((void **) &p->rec, need ? need : 16));
+        p->rec_bytes = need;
+    }
+    p->P.rec = p->rec;
+    // march: persistent 256-thread work-groups
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_march_kernel, 256, 0));
+    if (per_cu < 1)
+        per_cu = 1;
+    unsigned long long want = ((unsigned long long) p->n_rays + 255) / 256;
+    unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
+    const unsigned grid     = (unsigned) (want < cap ? want : cap);
+    // rays reserved per counter fetch: big enough to amortise the atomic, small enough
+    // that the last chunks balance (about 8 chunks per wave)
+    unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * 4 * 8) : 64;
+    ch                    = ch < 64 ? 64 : (ch > 512 ? 512 : ch);
+    p->P.chunk            = (unsigned) ((ch + 63) / 64 * 64);
+    HIP_TRY(hipEventRecord(p->ev0, stream));
+    if (grid > 0) {
+        hipLaunchKernelGGL(rt::rt_march_kernel, dim3(grid), dim3(256), 0, stream, p->P);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(p->evm, stream));
+    if (!(p->P.debug & 1u)) {
+        const int S = p->P.L * RT_N_SUB, K = p->P.K;
+        int rc;
+        if (S == 6) {
+            rc = (K % 4 == 0) ? launch_freq<6, 4>(p, stream, 0)
+                              : (K % 2 == 0 ? launch_freq<6, 2>(p, stream, 0) : launch_freq<6, 1>(p, stream, 0));
+        } else {
+            rc = (K % 4 == 0) ? launch_freq<0, 4>(p, stream, 0)
+                              : (K % 2 == 0 ? launch_freq<0, 2>(p, stream, 0) : launch_freq<0, 1>(p, stream, 0));
+        }
+        if (rc != RT_OK)
+            return rc;
+    }
+    HIP_TRY(hipEventRecord(p->ev1, stream));
+    return RT_OK;
+}
 
 extern "C" {
 
@@ -108,6 +185,10 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         (void) hipEventDestroy(p->ev0);
     if (p->ev1)
         (void) hipEventDestroy(p->ev1);
+    if (p->evm)
+        (void) hipEventDestroy(p->evm);
+    (void) hipFree(p->tan_dev);
+    (void) hipFree(p->rec);
     (void) hipFree(p->arena);
     (void) hipFree(p->rays_dev);
     (void) hipFree(p->grid_dev);
@@ -285,6 +366,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     PLAN_TRY(hipMalloc((void **) &p->ctl, sizeof(rt::DevCtl)));
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
+    PLAN_TRY(hipEventCreate(&p->evm));
+    if (const char *kname = getenv("RT_HIP_KERNEL"))
+        p->fused = strcmp(kname, "fused") == 0;
+    P.rec_stride = (unsigned) align_up((size_t) L * RT_N_SUB * 12 + sizeof(rt::RecMeta), 16);
     P.ctl = p->ctl;
     *out  = p;
     return RT_OK;
@@ -301,8 +386,20 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
         HIP_TRY(hipMalloc((void **) &p->rays_dev, n_rays * sizeof(rt_ray)));
         HIP_TRY(hipMemcpy(p->rays_dev, rays, n_rays * sizeof(rt_ray), hipMemcpyHostToDevice));
     }
+    (void) hipFree(p->tan_dev);
+    p->tan_dev = nullptr;
+    if (n_rays) {
+        // Helper.h:409-410 for every ray, at full lane occupancy, before the march
+        HIP_TRY(hipMalloc((void **) &p->tan_dev, n_rays * 2 * sizeof(float)));
+        const unsigned blocks = (unsigned) ((n_rays + 255) / 256);
+        hipLaunchKernelGGL(rt::rt_tan_kernel, dim3(blocks), dim3(256), 0, nullptr, p->rays_dev,
+                           (unsigned long long) n_rays, p->tan_dev);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     p->P.rays       = {};
     p->P.rays.list  = p->rays_dev;
+    p->P.rays.sxy   = p->tan_dev;
     p->P.rays.count = n_rays;
     p->n_rays       = n_rays;
     return RT_OK;
@@ -330,9 +427,22 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     memcpy(h.data() + ngx + ngy + nga, gb, sizeof(double) * (size_t) ngb);
     HIP_TRY(hipMalloc((void **) &p->grid_dev, nn * sizeof(double)));
     HIP_TRY(hipMemcpy(p->grid_dev, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    // Helper.h:409-410: tanf(1e-3f * ray.a) depends only on the grid value: nga + ngb
+    // evaluations on the host, with the same libm the CPU loop uses
+    std::vector<float> ht((size_t) nga + (size_t) ngb);
+    for (int k = 0; k < nga; k++)
+        ht[(size_t) k] = tanf(1e-3f * (float) ga[k]);
+    for (int m = 0; m < ngb; m++)
+        ht[(size_t) nga + (size_t) m] = tanf(1e-3f * (float) gb[m]);
+    (void) hipFree(p->tan_dev);
+    p->tan_dev = nullptr;
+    HIP_TRY(hipMalloc((void **) &p->tan_dev, ht.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(p->tan_dev, ht.data(), ht.size() * sizeof(float), hipMemcpyHostToDevice));
     rt::DevRays &R = p->P.rays;
     R              = {};
     R.list         = nullptr;
+    R.tan_a        = p->tan_dev;
+    R.tan_b        = p->tan_dev + nga;
     R.gx           = p->grid_dev;
     R.gy           = p->grid_dev + ngx;
     R.ga           = p->grid_dev + ngx + ngy;
@@ -415,6 +525,17 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     p->P.iang    = iang_dev;
     p->P.n_tiles = (unsigned) ((p->n_rays + rt::WAVE - 1) / rt::WAVE);
 
+    if (!p->fused) {
+        rc = plan_run_split(p, stream);
+        if (rc != RT_OK)
+            return rc;
+        p->last_stream = stream;
+        p->last_image  = image_dev;
+        p->last_iang   = iang_dev;
+        p->ran         = true;
+        return RT_OK;
+    }
+
     // launch geometry: persistent waves, 1..4 waves per workgroup by LDS slab size
     const size_t per_wave_lds = (size_t) p->P.L * RT_N_SUB * rt::WAVE * 12;
     int waves                 = (int) ((48 * 1024) / per_wave_lds);
@@ -472,6 +593,12 @@ int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int
         float ms          = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
         stats->kernel_ms = ms;
+        stats->march_ms  = 0.0f;
+        stats->freq_ms   = 0.0f;
+        if (!p->fused) {
+            HIP_TRY(hipEventElapsedTime(&stats->march_ms, p->ev0, p->evm));
+            HIP_TRY(hipEventElapsedTime(&stats->freq_ms, p->evm, p->ev1));
+        }
         stats->total_ms  = (float) std::chrono::duration<double, std::milli>(
                               std::chrono::steady_clock::now() - p->t_created).count();
     }
@@ -511,6 +638,24 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->last_stream));
     const size_t n = (size_t) p->n_rays, S = (size_t) p->P.L * RT_N_SUB;
+    if (!p->fused) {
+        // the march records themselves are the probe: de-interleave them
+        std::vector<unsigned char> h(n * p->P.rec_stride);
+        if (n)
+            HIP_TRY(hipMemcpy(h.data(), p->rec, h.size(), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < n; r++) {
+            const unsigned char *rec = h.data() + r * p->P.rec_stride;
+            if (gvl)
+                memcpy(gvl + r * S, rec, S * 4);
+            if (evl)
+                memcpy(evl + r * S, rec + S * 4, S * 4);
+            if (ivl)
+                memcpy(ivl + r * S, rec + S * 8, S * 4);
+        }
+        gvl = nullptr;
+        evl = nullptr;
+        ivl = nullptr;
+    }
     if (gvl)
         HIP_TRY(hipMemcpy(gvl, p->P.probe.gvl, n * S * 4, hipMemcpyDeviceToHost));
     if (evl)

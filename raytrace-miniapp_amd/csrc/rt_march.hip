@@ -1,0 +1,405 @@
+// rt_march.hip -- kernel A: the float32 ray march (Helper.h:404-513) as a
+// persistent-lane state machine.
+//
+// Why not "one lane marches one ray of a 64-ray tile": the reference's three
+// nested data-dependent loops (cell loop :463, cross-cell loop :326, integrator
+// loop :279) leave a wave64 running the innermost loop at 26 % lane occupancy
+// (measured, tools/loop_occupancy.py) -- lanes wait for the slowest ray at every
+// nesting level and for the longest ray of the tile.  Here a lane never waits:
+//   * a lane whose ray is finished immediately takes the next ray of the wave's
+//     reserved chunk (one global atomic per `chunk` rays, not per ray);
+//   * the nest is flattened: every wave iteration runs three predicated blocks
+//     [A] cell-loop bookkeeping + cell setup, [B] cross-cell setup, [C] one
+//     integrator step, with the loop-exit tests evaluated eagerly at the end of
+//     [C] so that every live lane performs exactly one integrator step per
+//     iteration.  The arithmetic and its order are exactly those of the nested
+//     loops (the march record is bit-identical to the CPU loop).
+// The per-ray record (gvl/evl/ivl + exit state) goes to HBM/L2 as one 96-byte
+// line per ray; rt_freq.hip consumes it with lanes = rays at full occupancy.
+#include "rt_math.h"
+
+namespace rt {
+
+enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 };
+
+// start ray of flat index ridx: position, and tangent of the launch angles
+__device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray &ray, float &ta, float &tb,
+                                         bool want_tan)
+{
+    if (R.list) {
+        ray = R.list[ridx];
+        if (want_tan) {
+            ta = R.sxy[2 * (size_t) ridx];
+            tb = R.sxy[2 * (size_t) ridx + 1];
+        }
+    } else {
+        // RayTraceImage.cpp:300-328: b fastest, then a, y, x; grids rounded to float
+        unsigned ijkm = (unsigned) (R.first + (long long) ridx * R.stride);
+        unsigned m    = ijkm % (unsigned) R.ngb;
+        unsigned q    = ijkm / (unsigned) R.ngb;
+        unsigned k    = q % (unsigned) R.nga;
+        q /= (unsigned) R.nga;
+        unsigned j = q % (unsigned) R.ngy;
+        unsigned i = q / (unsigned) R.ngy;
+        ray.x      = (float) R.gx[i];
+        ray.y      = (float) R.gy[j];
+        ray.a      = (float) R.ga[k];
+        ray.b      = (float) R.gb[m];
+        if (want_tan) {
+            ta = R.tan_a[k];
+            tb = R.tan_b[m];
+        }
+    }
+}
+
+// list mode: tangents of the launch angles (Helper.h:409-410), f64 tan rounded to
+// float == tanf on the angle range (tests/test_float_identities.py)
+extern "C" __global__ void __launch_bounds__(256) rt_tan_kernel(const rt_ray *rays, unsigned long long n, float *sxy)
+{
+    unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        rt_ray r       = rays[i];
+        sxy[2 * i]     = (float) tan((double) (1e-3f * r.a));
+        sxy[2 * i + 1] = (float) tan((double) (1e-3f * r.b));
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParams P)
+{
+    const int lane        = lane_id();
+    const int L           = P.L;
+    const int S           = L * RT_N_SUB;
+    const unsigned n_rays = (unsigned) P.rays.count;
+    const bool backward   = P.method == 1;
+    const bool use_emis   = P.use_emis != 0;
+    const unsigned CH     = P.chunk;
+    const int REFILL      = 8; // refill when this many lanes are idle (or the wave is empty)
+
+    unsigned chunk_next = 0, chunk_end = 0; // wave-uniform window of reserved ray indices
+    bool more           = true;             // wave-uniform: the global counter is not exhausted
+
+    // ---- per-lane state ----
+    int st        = ST_IDLE;
+    unsigned ridx = 0;
+    unsigned char *rec = nullptr;
+    int seg = 0, iz = 0, ii = 0;
+    float z = 0.0f, z_stop = 0.0f;
+    float px = 0, py = 0, pz = 0, sx = 0, sy = 0, sz = 1;
+    float gacc = 0, eacc = 0;
+    int cell_last = 0;
+    unsigned steps = 0;
+    bool escaped = false, any_nz = false, mirror = false;
+    // cell
+    double xc0 = 0, yc0 = 0, n00 = 0, n10 = 0, n01 = 0, n11 = 0;
+    float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
+    int c00 = 0;
+    float dzrem = 0, zc = 0, path = 0;
+    // integrator
+    float rx = 0, ry = 0, rz = 0, n = 0, n0 = 0, gxn = 0, gyn = 0, lim2 = 0, dzcap = 0, hsum = 0;
+    // totals of this lane over the whole launch
+    unsigned tot_steps_lo = 0, tot_esc = 0, tot_rays = 0, tot_skip = 0;
+    unsigned long long tot_steps = 0;
+#ifdef RT_INSTRUMENT
+    Inst inst;
+#endif
+
+    for (;;) {
+        // ------------------------------------------------------------ refill
+        const unsigned long long idle = __ballot(st == ST_IDLE);
+        const int n_idle              = (int) __popcll(idle);
+        if (n_idle == WAVE && !more)
+            break;
+        if (more && (n_idle >= REFILL)) {
+            const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (idle >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned) idle, 0u));
+            int need = n_idle, off = 0;
+            bool got = false;
+            while (need > 0) {
+                if (chunk_next == chunk_end) {
+                    unsigned base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&P.ctl->next_tile, CH);
+                    base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+                    if (base >= n_rays) {
+                        more = false;
+                        break;
+                    }
+                    chunk_next = base;
+                    chunk_end  = (n_rays - base < CH) ? n_rays : base + CH;
+                }
+                int avail = (int) (chunk_end - chunk_next);
+                int take  = avail < need ? avail : need;
+                if (st == ST_IDLE && !got && rank >= off && rank < off + take) {
+                    ridx = chunk_next + (unsigned) (rank - off);
+                    got  = true;
+                }
+                chunk_next += (unsigned) take;
+                need -= take;
+                off += take;
+            }
+            if (got) {
+                // Helper.h:404-418
+                rt_ray ray;
+                float ta = 0, tb = 0;
+                load_ray(P.rays, ridx, ray, ta, tb, true);
+                px = ray.x;
+                py = ray.y;
+                pz = 0.0f;
+                sx = ta;
+                sy = tb;
+                sz = 1.0f;
+                if (backward) {
+                    sx = -sx;
+                    sy = -sy;
+                    sz = -sz;
+                }
+                renormalise(sx, sy, sz);
+                rec       = P.rec + (size_t) ridx * P.rec_stride;
+                seg       = 0;
+                iz        = 0;
+                ii        = backward ? P.N - 1 : 1;
+                z         = 0.0f;
+                z_stop    = (P.dz0 * (0.0f + 1.0f) / RT_N_SUB);
+                gacc      = 0.0f;
+                eacc      = 0.0f;
+                cell_last = 0;
+                steps     = 0;
+                escaped   = false;
+                any_nz    = false;
+                st        = ST_CELL;
+            }
+        }
+        if (__ballot(st != ST_IDLE) == 0ull) {
+            if (!more)
+                break;
+            continue;
+        }
+
+        // ------------------------------------------------------------ [A] cell loop (Helper.h:430-504)
+        if (st == ST_CELL) {
+            for (;;) {
+                if (!escaped && z < 0.995f * z_stop) {
+                    const DevGain *G = &P.gain[ii];
+                    const float lo_x = G->lo_x, hi_x = G->hi_x, lo_y = G->lo_y, hi_y = G->hi_y;
+                    if (px < lo_x || px > hi_x || py < lo_y || py > hi_y || (double) (sz * sz) < 0.01) {
+                        escaped = true;
+                        continue;
+                    }
+                    mirror           = G->mirror_y != 0;
+                    const double *gx = G->x;
+                    const double *gy = G->y;
+                    const Node *node = G->node;
+                    const int Nx     = G->Nx;
+                    float ya         = mirror ? fabsf(py) : py;
+                    uint32_t k1      = interval_index(gx, (uint32_t) Nx, (double) px, G->inv_hx);
+                    uint32_t k2      = interval_index(gy, (uint32_t) G->Ny, (double) ya, G->inv_hy);
+                    c00              = (int) ((k1 - 1) + (k2 - 1) * (uint32_t) Nx);
+                    xc0              = gx[k1 - 1];
+                    yc0              = gy[k2 - 1];
+                    const double xc1 = gx[k1], yc1 = gy[k2];
+                    const Node a00 = node[c00], a10 = node[c00 + 1];
+                    const Node a01 = node[c00 + Nx], a11 = node[c00 + Nx + 1];
+                    const double hx = xc1 - xc0, hy = yc1 - yc0;
+                    const float u   = (float) (((double) px - xc0) / hx);
+                    const float v   = (float) (((double) ya - yc0) / hy);
+                    g0              = lerp2(u, v, a00.g0, a10.g0, a01.g0, a11.g0);
+                    E0              = 0.0f;
+                    if (use_emis) {
+                        E0 = lerp2(u, v, a00.E0, a10.E0, a01.E0, a11.E0);
+                        E0 = E0 >= 0 ? E0 : 0.0f;
+                    }
+                    n00 = a00.n;
+                    n10 = a10.n;
+                    n01 = a01.n;
+                    n11 = a11.n;
+                    wx  = (float) hx; // Helper.h:323-324
+                    wy  = (float) hy;
+                    b0  = (float) (xc0 - 0.1 * hx);
+                    b1  = (float) (xc1 + 0.1 * hx);
+                    b2  = (float) (yc0 - 0.1 * hy);
+                    b3  = (float) (yc1 + 0.1 * hy);
+                    if (mirror && k2 <= 1)
+                        b2 = -b3;
+                    pz    = 0.0f;
+                    zc    = 0.0f;
+                    path  = 0.0f;
+                    dzrem = z_stop - z;
+                    if (px > b0 && px < b1 && ya > b2 && ya < b3 && (double) zc < 0.999 * (double) dzrem) {
+                        st = ST_XSETUP;
+                        break;
+                    }
+                    // no cross-cell iteration at all: the cell step still counts (Helper.h:498-503)
+                    z += fabsf(pz);
+                    gacc += g0 * path;
+                    eacc += E0 * path;
+                    cell_last = c00;
+                    steps++;
+                    RT_TICK(2);
+                    continue;
+                }
+                // end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0)
+                {
+                    const int is   = backward ? RT_N_SUB - iz - 1 : iz;
+                    const int slot = (ii - 1) * RT_N_SUB + is;
+                    reinterpret_cast<float *>(rec)[slot]        = gacc;
+                    reinterpret_cast<float *>(rec)[S + slot]    = eacc;
+                    reinterpret_cast<int *>(rec)[2 * S + slot]  = cell_last;
+                    any_nz = any_nz || gacc != 0.0f || eacc != 0.0f;
+                }
+                gacc      = 0.0f;
+                eacc      = 0.0f;
+                cell_last = 0;
+                if (escaped) {
+                    // the remaining sub-segments are never entered: their slots stay zero
+                    int q = seg * RT_N_SUB + iz + 1;
+                    for (; q < S; q++) {
+                        const int sg = q / RT_N_SUB, zz = q - sg * RT_N_SUB;
+                        const int i2 = backward ? P.N - sg - 1 : sg + 1;
+                        const int s2 = (i2 - 1) * RT_N_SUB + (backward ? RT_N_SUB - zz - 1 : zz);
+                        reinterpret_cast<float *>(rec)[s2]         = 0.0f;
+                        reinterpret_cast<float *>(rec)[S + s2]     = 0.0f;
+                        reinterpret_cast<int *>(rec)[2 * S + s2]   = 0;
+                    }
+                    st = ST_DONE;
+                    break;
+                }
+                if (++iz == RT_N_SUB) {
+                    iz = 0;
+                    if (++seg == L) {
+                        st = ST_DONE;
+                        break;
+                    }
+                    ii = backward ? P.N - seg - 1 : seg + 1;
+                    z  = 0.0f;
+                }
+                z_stop = (P.dz0 * ((float) iz + 1.0f) / RT_N_SUB);
+            }
+        }
+
+        // ------------------------------------------------------------ ray finished
+        if (st == ST_DONE) {
+            unsigned fl = F_VALID;
+            if (escaped)
+                fl |= F_ESCAPED;
+            if (use_emis && !any_nz)
+                fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0
+            RecMeta m;
+            m.px          = px;
+            m.py          = py;
+            m.sx          = sx;
+            m.sy          = sy;
+            m.sz          = sz;
+            m.flags_steps = fl | (steps << 8);
+            *reinterpret_cast<RecMeta *>(rec + 12 * (size_t) S) = m;
+            tot_steps += steps;
+            tot_esc += escaped ? 1u : 0u;
+            tot_skip += (fl & F_SKIP) ? 1u : 0u;
+            tot_rays++;
+            st = ST_IDLE;
+        }
+
+        // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
+        if (st == ST_XSETUP) {
+            const float ya = mirror ? fabsf(py) : py;
+            const float u  = (float) (((double) px - xc0) / (double) wx);
+            const float v  = (float) (((double) ya - yc0) / (double) wy);
+            n0  = lerp2(u, v, (float) n00, (float) n10, (float) n01, (float) n11);
+            gxn = (float) ((1.0 - (double) v) * (n10 - n00) / (double) wx + (double) v * (n11 - n01) / (double) wx);
+            gyn = (float) ((1.0 - (double) u) * (n01 - n00) / (double) wy + (double) u * (n11 - n10) / (double) wy);
+            if (mirror && py < 0)
+                gyn = -gyn;
+            lim2  = dzrem - zc;
+            dzcap = 0.5f * 1.00001f * lim2; // Helper.h:274 with c = 0.5
+            rx    = 0.0f;
+            ry    = 0.0f;
+            rz    = 0.0f;
+            n     = n0;
+            hsum  = 0.0f;
+            st    = ST_STEP;
+            RT_TICK(1);
+        }
+
+        // ------------------------------------------------------------ [C] one integrator step (Helper.h:279-311)
+        if (st == ST_STEP) {
+            const float c    = 0.5f;
+            const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
+            bool run = fabsf(rx) < lim0 && fabsf(ry) < lim1 && fabsf(rz) < lim2 && (double) fabsf(n - n0) < 0.05;
+            if (run) {
+                n        = n0 + rx * gxn + ry * gyn;
+                float t  = (sx * gxn + sy * gyn + 1e-12f) / n;
+                float fx = gxn / n - sx * t;
+                float fy = gyn / n - sy * t;
+                float fz = -sz * t;
+                float h  = c * 0.1f / fabsf(t);
+                h        = h < dzcap ? h : dzcap;
+                float h2 = 1.0001f * (lim2 - fabsf(rz)) / fabsf(sz);
+                float h3 = c * 0.05f * (fabsf(sx) + 5e-4f) / (fabsf(fx) + 1e-8f);
+                float h4 = c * 0.05f * (fabsf(sy) + 5e-4f) / (fabsf(fy) + 1e-8f);
+                h        = h < h2 ? h : h2;
+                h        = h < h3 ? h : h3;
+                h        = h < h4 ? h : h4;
+                float ht = h * t;
+                float c1 = 0.5f * h * h * (1.0f - ht / 3.0f + ht * ht / 12.0f);
+                rx += sx * h + c1 * fx;
+                ry += sy * h + c1 * fy;
+                rz += sz * h + c1 * fz;
+                float c2 = h * (1.0f - 0.5f * ht + ht * ht / 6.0f);
+                sx += c2 * fx;
+                sy += c2 * fy;
+                sz += c2 * fz;
+                renormalise(sx, sy, sz);
+                hsum += h;
+                RT_TICK(0);
+                run = fabsf(rx) < lim0 && fabsf(ry) < lim1 && fabsf(rz) < lim2 && (double) fabsf(n - n0) < 0.05;
+            }
+            if (!run) {
+                // integrator loop over: close this cross-cell iteration (Helper.h:343-348)
+                path += hsum;
+                px += rx;
+                py += ry;
+                pz += rz;
+                zc += fabsf(rz);
+                const float ya = mirror ? fabsf(py) : py;
+                if (px > b0 && px < b1 && ya > b2 && ya < b3 && (double) zc < 0.999 * (double) dzrem) {
+                    st = ST_XSETUP;
+                } else {
+                    // cross-cell loop over: close the cell step (Helper.h:499-503)
+                    z += fabsf(pz);
+                    gacc += g0 * path;
+                    eacc += E0 * path;
+                    cell_last = c00;
+                    steps++;
+                    RT_TICK(2);
+                    st = ST_CELL;
+                }
+            }
+        }
+    }
+
+    // ---- launch totals ----
+    (void) tot_steps_lo;
+    {
+        unsigned long long s = tot_steps;
+        unsigned lo = wave_sum_u32((unsigned) (s & 0xffffffffu) >> 16), lo2 = wave_sum_u32((unsigned) (s & 0xffffu));
+        unsigned hi = wave_sum_u32((unsigned) (s >> 32));
+        unsigned e  = wave_sum_u32(tot_esc), k = wave_sum_u32(tot_skip), r = wave_sum_u32(tot_rays);
+        if (lane == 0) {
+            unsigned long long total = ((unsigned long long) hi << 32) + ((unsigned long long) lo << 16) + lo2;
+            atomicAdd(&P.ctl->cell_steps, total);
+            atomicAdd(&P.ctl->n_escaped, (unsigned long long) e);
+            atomicAdd(&P.ctl->n_skipped, (unsigned long long) k);
+            atomicAdd(&P.ctl->n_rays, (unsigned long long) r);
+        }
+#ifdef RT_INSTRUMENT
+        for (int i = 0; i < 3; i++) {
+            unsigned tw = wave_sum_u32(inst.w[i]), ta = wave_sum_u32(inst.a[i]);
+            if (lane == 0) {
+                atomicAdd(&g_inst[2 * i], (unsigned long long) tw);
+                atomicAdd(&g_inst[2 * i + 1], (unsigned long long) ta);
+            }
+        }
+#endif
+    }
+}
+
+} // namespace rt

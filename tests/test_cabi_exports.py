@@ -49,7 +49,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(c.RtBeam) == 5 * 4 + 4 + 5 * 8 + 5 * 8     # ints, pad, doubles, pointers
     assert ctypes.sizeof(c.RtGain) == 3 * 4 + 4 + 6 * 8
     assert ctypes.sizeof(c.RtSeed) == 5 * 4 + 4 + 10 * 8 + 8
-    assert ctypes.sizeof(c.RtStats) == 4 * 8 + 2 * 4
+    assert ctypes.sizeof(c.RtStats) == 4 * 8 + 4 * 4
 
 
 def test_no_silent_fallback_without_a_device(lib, ase_small):
