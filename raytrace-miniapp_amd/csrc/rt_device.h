@@ -40,6 +40,22 @@ struct DevGain {
     double inv_hx, inv_hy; // (Nx-1)/(x[Nx-1]-x[0]): index guess for uniform grids
 };
 
+// Header of one length inside the "march blob": everything the march gathers, laid
+// out so that a work-group can copy the whole blob into LDS verbatim.
+//   blob = BlobGain[N] | per length: x[Nx] (f64) | y[Ny] (f64) | rx[Nx] | ry[Ny] | Node[Nx*Ny]
+// rx[k] = {1/(x[k]-x[k-1]), 1/(double)(float)(x[k]-x[k-1])}: the correctly rounded
+// reciprocals of the two divisors a cell uses (Helper.h:482-483 and :323,330-334),
+// computed once on the host with IEEE division so that the kernel divides by
+// multiplication + exact residual correction (rt_math.h, div_by_recip).
+// off_* are byte offsets from the start of the blob (16-byte aligned).
+struct alignas(16) BlobGain {
+    float lo_x, hi_x, lo_y, hi_y; // plasma box as floats (Helper.h:445-453), lo_y = -hi_y if mirrored
+    int Nx, Ny, mirror_y, off_x;
+    int off_y, off_node, off_rx, off_ry;
+    double x0, y0;                // x[0], y[0]
+    double inv_hx, inv_hy;        // (Nx-1)/(x[Nx-1]-x[0]): index guess on uniform grids
+};
+
 struct DevSeed {
     const double *x[5];
     const double *f[5];
@@ -115,6 +131,9 @@ struct DevParams {
     unsigned int n_tiles;
     unsigned int debug; // bit0: skip phase B (profiling only, RT_HIP_DEBUG env)
     // two-kernel path (rt_march.hip -> records -> rt_freq.hip)
+    const unsigned char *blob; // march blob (global copy)
+    unsigned int blob_bytes;
+    unsigned int pad2;
     unsigned char *rec;
     unsigned int rec_stride;
     unsigned int chunk; // rays a wave reserves per fetch of the global ray counter

@@ -129,21 +129,36 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     }
     p->P.rec = p->rec;
     // march: persistent 256-thread work-groups
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_march_kernel, 256, 0));
+    // LDS variant: the whole march blob in LDS, one 1024-thread work-group per CU;
+    // global variant when the blob does not fit (RT_HIP_MARCH=global forces it)
+    const char *force   = getenv("RT_HIP_MARCH");
+    const bool lds_tab  = p->P.blob_bytes <= 152 * 1024 && !(force && strcmp(force, "global") == 0);
+    const unsigned bthr = lds_tab ? 1024u : 256u;
+    const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
+    int per_cu          = 0;
+    if (lds_tab) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt::rt_march_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) mlds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_march_kernel<true>, (int) bthr, mlds));
+    } else {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_march_kernel<false>, (int) bthr, mlds));
+    }
     if (per_cu < 1)
         per_cu = 1;
-    unsigned long long want = ((unsigned long long) p->n_rays + 255) / 256;
+    unsigned long long want = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
     unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
     const unsigned grid     = (unsigned) (want < cap ? want : cap);
     // rays reserved per counter fetch: big enough to amortise the atomic, small enough
     // that the last chunks balance (about 8 chunks per wave)
-    unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * 4 * 8) : 64;
+    unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
     ch                    = ch < 64 ? 64 : (ch > 512 ? 512 : ch);
     p->P.chunk            = (unsigned) ((ch + 63) / 64 * 64);
     HIP_TRY(hipEventRecord(p->ev0, stream));
     if (grid > 0) {
-        hipLaunchKernelGGL(rt::rt_march_kernel, dim3(grid), dim3(256), 0, stream, p->P);
+        if (lds_tab)
+            hipLaunchKernelGGL(rt::rt_march_kernel<true>, dim3(grid), dim3(bthr), mlds, stream, p->P);
+        else
+            hipLaunchKernelGGL(rt::rt_march_kernel<false>, dim3(grid), dim3(bthr), mlds, stream, p->P);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(p->evm, stream));
@@ -304,6 +319,52 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         }
     }
     const size_t off_gain = ab.reserve(sizeof(rt::DevGain) * (size_t) N);
+    // march blob: headers + grids + fused corner nodes of every length, copied to LDS
+    // verbatim by rt_march_kernel<true>
+    std::vector<unsigned char> blob(align_up(sizeof(rt::BlobGain) * (size_t) N, 16));
+    for (int i = 1; i < N; i++) {
+        const rt_gain &g  = gain[i];
+        const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
+        rt::BlobGain h;
+        memset(&h, 0, sizeof(h));
+        h.lo_x     = dg[(size_t) i].lo_x;
+        h.hi_x     = dg[(size_t) i].hi_x;
+        h.lo_y     = dg[(size_t) i].lo_y;
+        h.hi_y     = dg[(size_t) i].hi_y;
+        h.Nx       = g.Nx;
+        h.Ny       = g.Ny;
+        h.mirror_y = dg[(size_t) i].mirror_y;
+        h.x0       = g.x[0];
+        h.y0       = g.y[0];
+        h.inv_hx   = dg[(size_t) i].inv_hx;
+        h.inv_hy   = dg[(size_t) i].inv_hy;
+        h.off_x    = (int) blob.size();
+        blob.resize(align_up(blob.size() + sizeof(double) * (size_t) g.Nx, 16));
+        memcpy(blob.data() + h.off_x, g.x, sizeof(double) * (size_t) g.Nx);
+        h.off_y = (int) blob.size();
+        blob.resize(align_up(blob.size() + sizeof(double) * (size_t) g.Ny, 16));
+        memcpy(blob.data() + h.off_y, g.y, sizeof(double) * (size_t) g.Ny);
+        // reciprocal pairs per grid interval (entry 0 unused)
+        auto put_recips = [&](const double *gp, int n) {
+            const int off = (int) blob.size();
+            blob.resize(blob.size() + 16 * (size_t) n);
+            double *r = reinterpret_cast<double *>(blob.data() + off);
+            r[0] = r[1] = 0.0;
+            for (int k = 1; k < n; k++) {
+                const double hk = gp[k] - gp[k - 1];
+                r[2 * k]        = 1.0 / hk;
+                r[2 * k + 1]    = 1.0 / (double) (float) hk;
+            }
+            return off;
+        };
+        h.off_rx   = put_recips(g.x, g.Nx);
+        h.off_ry   = put_recips(g.y, g.Ny);
+        h.off_node = (int) blob.size();
+        blob.resize(blob.size() + sizeof(rt::Node) * npix);
+        memcpy(blob.data() + h.off_node, ab.host.data() + goff[i].node, sizeof(rt::Node) * npix);
+        memcpy(blob.data() + sizeof(rt::BlobGain) * (size_t) i, &h, sizeof(h));
+    }
+    const size_t off_blob = ab.put(blob.data(), blob.size());
 
 #define PLAN_TRY(expr)                                   \
     do {                                                 \
@@ -358,6 +419,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         P.seed.f0 = seed->f0;
     }
     P.gain = reinterpret_cast<const rt::DevGain *>(A + off_gain);
+    P.blob       = A + off_blob;
+    P.blob_bytes = (unsigned) blob.size();
     if (const char *dbg = getenv("RT_HIP_DEBUG"))
         P.debug = (unsigned) strtoul(dbg, nullptr, 0);
 

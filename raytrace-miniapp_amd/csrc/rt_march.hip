@@ -1,5 +1,5 @@
 // rt_march.hip -- kernel A: the float32 ray march (Helper.h:404-513) as a
-// persistent-lane state machine.
+// persistent-lane state machine over LDS-resident plasma tables.
 //
 // Why not "one lane marches one ray of a 64-ray tile": the reference's three
 // nested data-dependent loops (cell loop :463, cross-cell loop :326, integrator
@@ -12,13 +12,24 @@
 //     [A] cell-loop bookkeeping + cell setup, [B] cross-cell setup, [C] one
 //     integrator step, with the loop-exit tests evaluated eagerly at the end of
 //     [C] so that every live lane performs exactly one integrator step per
-//     iteration.  The arithmetic and its order are exactly those of the nested
-//     loops (the march record is bit-identical to the CPU loop).
-// The per-ray record (gvl/evl/ivl + exit state) goes to HBM/L2 as one 96-byte
-// line per ray; rt_freq.hip consumes it with lanes = rays at full occupancy.
+//     iteration (93 % occupancy of the integrator step, measured).  The arithmetic
+//     and its order are exactly those of the nested loops: the march record is
+//     bit-identical to the CPU loop.
+// Tables: what a cell-step gathers -- grid coordinates and the fused
+// {n, g0, E0} corner nodes of every length -- is one "march blob" (rt_device.h)
+// that each work-group copies into LDS once (LDS variant, one work-group per CU)
+// so that the dependent index -> coordinate -> corner read chain of block [A] costs
+// LDS latency, not three L2 round trips; a blob too large for LDS is read in
+// place (global variant).  The per-ray record (gvl/evl/ivl + exit state) leaves
+// as one 96-byte line per ray; rt_freq.hip consumes it with lanes = rays.
 #include "rt_math.h"
 
 namespace rt {
+
+struct alignas(16) Recip2 {
+    double rh; // 1 / (g[k] - g[k-1])
+    double rw; // 1 / (double) (float) (g[k] - g[k-1])
+};
 
 enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 };
 
@@ -64,8 +75,40 @@ extern "C" __global__ void __launch_bounds__(256) rt_tan_kernel(const rt_ray *ra
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParams P)
+// Helper.h:131-143 on a blob grid.  The bisection returns the unique u in
+// [1, n-1] with (u == 1 || g[u-1] < v) && (u == n-1 || g[u] >= v) on a
+// non-decreasing grid: guess u arithmetically (exact on the uniform grids the
+// files hold), verify with the two coordinates the cell-step needs anyway, and
+// only bisect when the guess fails.  Returns u and g[u-1], g[u].
+__device__ __forceinline__ uint32_t find_interval(const double *g, int n, double g0, double inv_h, double v,
+                                                  double &c_lo, double &c_hi)
 {
+    const int last = n - 1;
+    int u          = (int) ((v - g0) * inv_h) + 1;
+    u              = u < 1 ? 1 : (u > last ? last : u);
+    c_lo           = g[u - 1];
+    c_hi           = g[u];
+    const bool ok  = (u == 1 || c_lo < v) && (u == last || c_hi >= v);
+    if (!ok) {
+        int lo = 0, hi = last;
+        while (hi - lo != 1) {
+            int mid = (hi + lo) / 2;
+            if (g[mid] >= v)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        u    = hi;
+        c_lo = g[u - 1];
+        c_hi = g[u];
+    }
+    return (uint32_t) u;
+}
+
+template <bool LDS_TAB>
+__global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane        = lane_id();
     const int L           = P.L;
     const int S           = L * RT_N_SUB;
@@ -75,13 +118,26 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
     const unsigned CH     = P.chunk;
     const int REFILL      = 8; // refill when this many lanes are idle (or the wave is empty)
 
+    // ---- tables: copy the march blob to LDS once per work-group ----
+    const unsigned char *tab;
+    if (LDS_TAB) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.blob);
+        uint4 *dst       = reinterpret_cast<uint4 *>(lds_raw);
+        for (unsigned i = threadIdx.x; i < P.blob_bytes / 16; i += blockDim.x)
+            dst[i] = src[i];
+        __syncthreads();
+        tab = lds_raw;
+    } else {
+        tab = P.blob;
+    }
+    const BlobGain *hdr = reinterpret_cast<const BlobGain *>(tab);
+
     unsigned chunk_next = 0, chunk_end = 0; // wave-uniform window of reserved ray indices
     bool more           = true;             // wave-uniform: the global counter is not exhausted
 
     // ---- per-lane state ----
     int st        = ST_IDLE;
     unsigned ridx = 0;
-    unsigned char *rec = nullptr;
     int seg = 0, iz = 0, ii = 0;
     float z = 0.0f, z_stop = 0.0f;
     float px = 0, py = 0, pz = 0, sx = 0, sy = 0, sz = 1;
@@ -89,16 +145,15 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
     int cell_last = 0;
     unsigned steps = 0;
     bool escaped = false, any_nz = false, mirror = false;
-    // cell
-    double xc0 = 0, yc0 = 0, n00 = 0, n10 = 0, n01 = 0, n11 = 0;
+    // cell (corner values are re-read from the blob in block [B])
+    int k1 = 1, k2 = 1, c00 = 0;
+    double rwx = 1, rwy = 1; // 1/(double)wx, 1/(double)wy of the current cell
     float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
-    int c00 = 0;
     float dzrem = 0, zc = 0, path = 0;
     // integrator
     float rx = 0, ry = 0, rz = 0, n = 0, n0 = 0, gxn = 0, gyn = 0, lim2 = 0, dzcap = 0, hsum = 0;
     // totals of this lane over the whole launch
-    unsigned tot_steps_lo = 0, tot_esc = 0, tot_rays = 0, tot_skip = 0;
-    unsigned long long tot_steps = 0;
+    unsigned tot_steps = 0, tot_esc = 0, tot_rays = 0, tot_skip = 0;
 #ifdef RT_INSTRUMENT
     Inst inst;
 #endif
@@ -154,7 +209,6 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
                     sz = -sz;
                 }
                 renormalise(sx, sy, sz);
-                rec       = P.rec + (size_t) ridx * P.rec_stride;
                 seg       = 0;
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
@@ -176,136 +230,144 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
         }
 
         // ------------------------------------------------------------ [A] cell loop (Helper.h:430-504)
+        // Straight-line: at most one sub-segment end [A1] and one cell setup [A2] per wave
+        // iteration (a lane that needs more -- several empty sub-segments in a row, or the
+        // commit after an escape -- simply comes back next iteration).
         if (st == ST_CELL) {
-            for (;;) {
-                if (!escaped && z < 0.995f * z_stop) {
-                    const DevGain *G = &P.gain[ii];
-                    const float lo_x = G->lo_x, hi_x = G->hi_x, lo_y = G->lo_y, hi_y = G->hi_y;
-                    if (px < lo_x || px > hi_x || py < lo_y || py > hi_y || (double) (sz * sz) < 0.01) {
-                        escaped = true;
-                        continue;
+            unsigned char *rec = P.rec + (size_t) ridx * P.rec_stride;
+            bool in_seg        = !escaped & (z < 0.995f * z_stop);
+            if (!in_seg) {
+                // [A1] end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0)
+                const int is   = backward ? RT_N_SUB - iz - 1 : iz;
+                const int slot = (ii - 1) * RT_N_SUB + is;
+                reinterpret_cast<float *>(rec)[slot]       = gacc;
+                reinterpret_cast<float *>(rec)[S + slot]   = eacc;
+                reinterpret_cast<int *>(rec)[2 * S + slot] = cell_last;
+                any_nz    = any_nz | (gacc != 0.0f) | (eacc != 0.0f);
+                gacc      = 0.0f;
+                eacc      = 0.0f;
+                cell_last = 0;
+                if (escaped) {
+                    // the remaining sub-segments are never entered: their slots stay zero
+                    for (int q = seg * RT_N_SUB + iz + 1; q < S; q++) {
+                        const int sg = q / RT_N_SUB, zz = q - sg * RT_N_SUB;
+                        const int i2 = backward ? P.N - sg - 1 : sg + 1;
+                        const int s2 = (i2 - 1) * RT_N_SUB + (backward ? RT_N_SUB - zz - 1 : zz);
+                        reinterpret_cast<float *>(rec)[s2]       = 0.0f;
+                        reinterpret_cast<float *>(rec)[S + s2]   = 0.0f;
+                        reinterpret_cast<int *>(rec)[2 * S + s2] = 0;
                     }
-                    mirror           = G->mirror_y != 0;
-                    const double *gx = G->x;
-                    const double *gy = G->y;
-                    const Node *node = G->node;
-                    const int Nx     = G->Nx;
-                    float ya         = mirror ? fabsf(py) : py;
-                    uint32_t k1      = interval_index(gx, (uint32_t) Nx, (double) px, G->inv_hx);
-                    uint32_t k2      = interval_index(gy, (uint32_t) G->Ny, (double) ya, G->inv_hy);
-                    c00              = (int) ((k1 - 1) + (k2 - 1) * (uint32_t) Nx);
-                    xc0              = gx[k1 - 1];
-                    yc0              = gy[k2 - 1];
-                    const double xc1 = gx[k1], yc1 = gy[k2];
+                    st = ST_DONE;
+                } else {
+                    if (++iz == RT_N_SUB) {
+                        iz = 0;
+                        ++seg;
+                        ii = backward ? P.N - seg - 1 : seg + 1;
+                        z  = 0.0f;
+                    }
+                    if (seg == L) {
+                        st = ST_DONE;
+                    } else {
+                        z_stop = (P.dz0 * ((float) iz + 1.0f) / RT_N_SUB);
+                        in_seg = z < 0.995f * z_stop;
+                    }
+                }
+            }
+            if ((st == ST_CELL) & in_seg) {
+                // [A2] escape test + cell setup (Helper.h:465-497)
+                const BlobGain G = hdr[ii];
+                if ((px < G.lo_x) | (px > G.hi_x) | (py < G.lo_y) | (py > G.hi_y) | ((double) (sz * sz) < 0.01)) {
+                    escaped = true; // its slot is committed by [A1] next iteration
+                } else {
+                    mirror           = G.mirror_y != 0;
+                    const double *gx = reinterpret_cast<const double *>(tab + G.off_x);
+                    const double *gy = reinterpret_cast<const double *>(tab + G.off_y);
+                    const Node *node = reinterpret_cast<const Node *>(tab + G.off_node);
+                    const float ya   = mirror ? fabsf(py) : py;
+                    double xc0, xc1, yc0, yc1;
+                    k1  = (int) find_interval(gx, G.Nx, G.x0, G.inv_hx, (double) px, xc0, xc1);
+                    k2  = (int) find_interval(gy, G.Ny, G.y0, G.inv_hy, (double) ya, yc0, yc1);
+                    c00 = (k1 - 1) + (k2 - 1) * G.Nx;
                     const Node a00 = node[c00], a10 = node[c00 + 1];
-                    const Node a01 = node[c00 + Nx], a11 = node[c00 + Nx + 1];
+                    const Node a01 = node[c00 + G.Nx], a11 = node[c00 + G.Nx + 1];
                     const double hx = xc1 - xc0, hy = yc1 - yc0;
-                    const float u   = (float) (((double) px - xc0) / hx);
-                    const float v   = (float) (((double) ya - yc0) / hy);
+                    const Recip2 qx = reinterpret_cast<const Recip2 *>(tab + G.off_rx)[k1];
+                    const Recip2 qy = reinterpret_cast<const Recip2 *>(tab + G.off_ry)[k2];
+                    rwx             = qx.rw;
+                    rwy             = qy.rw;
+                    const float u   = (float) div_by_recip((double) px - xc0, hx, qx.rh);
+                    const float v   = (float) div_by_recip((double) ya - yc0, hy, qy.rh);
                     g0              = lerp2(u, v, a00.g0, a10.g0, a01.g0, a11.g0);
                     E0              = 0.0f;
                     if (use_emis) {
                         E0 = lerp2(u, v, a00.E0, a10.E0, a01.E0, a11.E0);
                         E0 = E0 >= 0 ? E0 : 0.0f;
                     }
-                    n00 = a00.n;
-                    n10 = a10.n;
-                    n01 = a01.n;
-                    n11 = a11.n;
-                    wx  = (float) hx; // Helper.h:323-324
-                    wy  = (float) hy;
-                    b0  = (float) (xc0 - 0.1 * hx);
-                    b1  = (float) (xc1 + 0.1 * hx);
-                    b2  = (float) (yc0 - 0.1 * hy);
-                    b3  = (float) (yc1 + 0.1 * hy);
+                    wx = (float) hx; // Helper.h:323-324
+                    wy = (float) hy;
+                    b0 = (float) (xc0 - 0.1 * hx);
+                    b1 = (float) (xc1 + 0.1 * hx);
+                    b2 = (float) (yc0 - 0.1 * hy);
+                    b3 = (float) (yc1 + 0.1 * hy);
                     if (mirror && k2 <= 1)
                         b2 = -b3;
                     pz    = 0.0f;
                     zc    = 0.0f;
                     path  = 0.0f;
                     dzrem = z_stop - z;
-                    if (px > b0 && px < b1 && ya > b2 && ya < b3 && (double) zc < 0.999 * (double) dzrem) {
+                    if ((px > b0) & (px < b1) & (ya > b2) & (ya < b3) & ((double) zc < 0.999 * (double) dzrem)) {
                         st = ST_XSETUP;
-                        break;
+                    } else {
+                        // no cross-cell iteration at all: the cell step still counts (Helper.h:498-503)
+                        z += fabsf(pz);
+                        gacc += g0 * path;
+                        eacc += E0 * path;
+                        cell_last = c00;
+                        steps++;
+                        RT_TICK(2);
                     }
-                    // no cross-cell iteration at all: the cell step still counts (Helper.h:498-503)
-                    z += fabsf(pz);
-                    gacc += g0 * path;
-                    eacc += E0 * path;
-                    cell_last = c00;
-                    steps++;
-                    RT_TICK(2);
-                    continue;
                 }
-                // end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0)
-                {
-                    const int is   = backward ? RT_N_SUB - iz - 1 : iz;
-                    const int slot = (ii - 1) * RT_N_SUB + is;
-                    reinterpret_cast<float *>(rec)[slot]        = gacc;
-                    reinterpret_cast<float *>(rec)[S + slot]    = eacc;
-                    reinterpret_cast<int *>(rec)[2 * S + slot]  = cell_last;
-                    any_nz = any_nz || gacc != 0.0f || eacc != 0.0f;
-                }
-                gacc      = 0.0f;
-                eacc      = 0.0f;
-                cell_last = 0;
-                if (escaped) {
-                    // the remaining sub-segments are never entered: their slots stay zero
-                    int q = seg * RT_N_SUB + iz + 1;
-                    for (; q < S; q++) {
-                        const int sg = q / RT_N_SUB, zz = q - sg * RT_N_SUB;
-                        const int i2 = backward ? P.N - sg - 1 : sg + 1;
-                        const int s2 = (i2 - 1) * RT_N_SUB + (backward ? RT_N_SUB - zz - 1 : zz);
-                        reinterpret_cast<float *>(rec)[s2]         = 0.0f;
-                        reinterpret_cast<float *>(rec)[S + s2]     = 0.0f;
-                        reinterpret_cast<int *>(rec)[2 * S + s2]   = 0;
-                    }
-                    st = ST_DONE;
-                    break;
-                }
-                if (++iz == RT_N_SUB) {
-                    iz = 0;
-                    if (++seg == L) {
-                        st = ST_DONE;
-                        break;
-                    }
-                    ii = backward ? P.N - seg - 1 : seg + 1;
-                    z  = 0.0f;
-                }
-                z_stop = (P.dz0 * ((float) iz + 1.0f) / RT_N_SUB);
             }
-        }
-
-        // ------------------------------------------------------------ ray finished
-        if (st == ST_DONE) {
-            unsigned fl = F_VALID;
-            if (escaped)
-                fl |= F_ESCAPED;
-            if (use_emis && !any_nz)
-                fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0
-            RecMeta m;
-            m.px          = px;
-            m.py          = py;
-            m.sx          = sx;
-            m.sy          = sy;
-            m.sz          = sz;
-            m.flags_steps = fl | (steps << 8);
-            *reinterpret_cast<RecMeta *>(rec + 12 * (size_t) S) = m;
-            tot_steps += steps;
-            tot_esc += escaped ? 1u : 0u;
-            tot_skip += (fl & F_SKIP) ? 1u : 0u;
-            tot_rays++;
-            st = ST_IDLE;
+            // ---------------------------------------------------------- ray finished
+            if (st == ST_DONE) {
+                unsigned fl = F_VALID;
+                if (escaped)
+                    fl |= F_ESCAPED;
+                if (use_emis && !any_nz)
+                    fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0
+                RecMeta m;
+                m.px          = px;
+                m.py          = py;
+                m.sx          = sx;
+                m.sy          = sy;
+                m.sz          = sz;
+                m.flags_steps = fl | (steps << 8);
+                *reinterpret_cast<RecMeta *>(rec + 12 * (size_t) S) = m;
+                tot_steps += steps;
+                tot_esc += escaped ? 1u : 0u;
+                tot_skip += (fl & F_SKIP) ? 1u : 0u;
+                tot_rays++;
+                st = ST_IDLE;
+            }
         }
 
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
-            const float ya = mirror ? fabsf(py) : py;
-            const float u  = (float) (((double) px - xc0) / (double) wx);
-            const float v  = (float) (((double) ya - yc0) / (double) wy);
+            const BlobGain G = hdr[ii];
+            const double xc0 = reinterpret_cast<const double *>(tab + G.off_x)[k1 - 1];
+            const double yc0 = reinterpret_cast<const double *>(tab + G.off_y)[k2 - 1];
+            const Node *node = reinterpret_cast<const Node *>(tab + G.off_node);
+            const double n00 = node[c00].n, n10 = node[c00 + 1].n;
+            const double n01 = node[c00 + G.Nx].n, n11 = node[c00 + G.Nx + 1].n;
+            const float ya   = mirror ? fabsf(py) : py;
+            const double dwx = (double) wx, dwy = (double) wy;
+            const float u    = (float) div_by_recip((double) px - xc0, dwx, rwx);
+            const float v    = (float) div_by_recip((double) ya - yc0, dwy, rwy);
             n0  = lerp2(u, v, (float) n00, (float) n10, (float) n01, (float) n11);
-            gxn = (float) ((1.0 - (double) v) * (n10 - n00) / (double) wx + (double) v * (n11 - n01) / (double) wx);
-            gyn = (float) ((1.0 - (double) u) * (n01 - n00) / (double) wy + (double) u * (n11 - n10) / (double) wy);
+            gxn = (float) (div_by_recip((1.0 - (double) v) * (n10 - n00), dwx, rwx) +
+                           div_by_recip((double) v * (n11 - n01), dwx, rwx));
+            gyn = (float) (div_by_recip((1.0 - (double) u) * (n01 - n00), dwy, rwy) +
+                           div_by_recip((double) u * (n11 - n10), dwy, rwy));
             if (mirror && py < 0)
                 gyn = -gyn;
             lim2  = dzrem - zc;
@@ -323,12 +385,13 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
         if (st == ST_STEP) {
             const float c    = 0.5f;
             const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
-            bool run = fabsf(rx) < lim0 && fabsf(ry) < lim1 && fabsf(rz) < lim2 && (double) fabsf(n - n0) < 0.05;
+            bool run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & ((double) fabsf(n - n0) < 0.05);
             if (run) {
                 n        = n0 + rx * gxn + ry * gyn;
-                float t  = (sx * gxn + sy * gyn + 1e-12f) / n;
-                float fx = gxn / n - sx * t;
-                float fy = gyn / n - sy * t;
+                const float rn = 1.0f / n; // one IEEE division, three exact quotients
+                float t  = div_by_recip(sx * gxn + sy * gyn + 1e-12f, n, rn);
+                float fx = div_by_recip(gxn, n, rn) - sx * t;
+                float fy = div_by_recip(gyn, n, rn) - sy * t;
                 float fz = -sz * t;
                 float h  = c * 0.1f / fabsf(t);
                 h        = h < dzcap ? h : dzcap;
@@ -339,18 +402,19 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
                 h        = h < h3 ? h : h3;
                 h        = h < h4 ? h : h4;
                 float ht = h * t;
-                float c1 = 0.5f * h * h * (1.0f - ht / 3.0f + ht * ht / 12.0f);
+                const float R3 = 1.0f / 3.0f, R6 = 1.0f / 6.0f, R12 = 1.0f / 12.0f; // RN(1/b), folded
+                float c1 = 0.5f * h * h * (1.0f - div_by_recip(ht, 3.0f, R3) + div_by_recip(ht * ht, 12.0f, R12));
                 rx += sx * h + c1 * fx;
                 ry += sy * h + c1 * fy;
                 rz += sz * h + c1 * fz;
-                float c2 = h * (1.0f - 0.5f * ht + ht * ht / 6.0f);
+                float c2 = h * (1.0f - 0.5f * ht + div_by_recip(ht * ht, 6.0f, R6));
                 sx += c2 * fx;
                 sy += c2 * fy;
                 sz += c2 * fz;
                 renormalise(sx, sy, sz);
                 hsum += h;
                 RT_TICK(0);
-                run = fabsf(rx) < lim0 && fabsf(ry) < lim1 && fabsf(rz) < lim2 && (double) fabsf(n - n0) < 0.05;
+                run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & ((double) fabsf(n - n0) < 0.05);
             }
             if (!run) {
                 // integrator loop over: close this cross-cell iteration (Helper.h:343-348)
@@ -360,7 +424,7 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
                 pz += rz;
                 zc += fabsf(rz);
                 const float ya = mirror ? fabsf(py) : py;
-                if (px > b0 && px < b1 && ya > b2 && ya < b3 && (double) zc < 0.999 * (double) dzrem) {
+                if ((px > b0) & (px < b1) & (ya > b2) & (ya < b3) & ((double) zc < 0.999 * (double) dzrem)) {
                     st = ST_XSETUP;
                 } else {
                     // cross-cell loop over: close the cell step (Helper.h:499-503)
@@ -377,15 +441,11 @@ extern "C" __global__ void __launch_bounds__(256) rt_march_kernel(const DevParam
     }
 
     // ---- launch totals ----
-    (void) tot_steps_lo;
     {
-        unsigned long long s = tot_steps;
-        unsigned lo = wave_sum_u32((unsigned) (s & 0xffffffffu) >> 16), lo2 = wave_sum_u32((unsigned) (s & 0xffffu));
-        unsigned hi = wave_sum_u32((unsigned) (s >> 32));
-        unsigned e  = wave_sum_u32(tot_esc), k = wave_sum_u32(tot_skip), r = wave_sum_u32(tot_rays);
+        unsigned s = wave_sum_u32(tot_steps), e = wave_sum_u32(tot_esc);
+        unsigned k = wave_sum_u32(tot_skip), r = wave_sum_u32(tot_rays);
         if (lane == 0) {
-            unsigned long long total = ((unsigned long long) hi << 32) + ((unsigned long long) lo << 16) + lo2;
-            atomicAdd(&P.ctl->cell_steps, total);
+            atomicAdd(&P.ctl->cell_steps, (unsigned long long) s);
             atomicAdd(&P.ctl->n_escaped, (unsigned long long) e);
             atomicAdd(&P.ctl->n_skipped, (unsigned long long) k);
             atomicAdd(&P.ctl->n_rays, (unsigned long long) r);

@@ -81,6 +81,38 @@ __device__ __forceinline__ void renormalise(float &sx, float &sy, float &sz)
     sz *= inv;
 }
 
+// Division by a divisor whose correctly rounded reciprocal y = RN(1/b) is known:
+// q = RN(a*y), r = a - b*q (exact with FMA), result RN(q + r*y) = RN(a/b)
+// (Markstein's correction step).  Checked against IEEE division on the CPU by
+// tests/test_float_identities.py (1e9 random pairs, and every float for the
+// constant divisors); two cases are routed away from the correction because it
+// is not exact there: a zero residual keeps q (preserves the sign of a zero
+// quotient), and quotients in or near the subnormal range take a true division.
+__device__ __forceinline__ float div_by_recip(float a, float b, float y)
+{
+    const float q = a * y;
+    const float r = fmaf(-b, q, a);
+    float c       = fmaf(r, y, q);
+    c             = (r == 0.0f) ? q : c;
+    if (fabsf(a) < 1e-30f && a != 0.0f) {
+        asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
+        c = a / b;
+    }
+    return c;
+}
+__device__ __forceinline__ double div_by_recip(double a, double b, double y)
+{
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    double c       = fma(r, y, q);
+    c              = (r == 0.0) ? q : c;
+    if (fabs(a) < 1e-290 && a != 0.0) {
+        asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
+        c = a / b;
+    }
+    return c;
+}
+
 // Helper.h:153-158
 __device__ __forceinline__ float lerp2(float u, float v, float f00, float f10, float f01, float f11)
 {
