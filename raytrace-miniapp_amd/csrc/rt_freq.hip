@@ -24,15 +24,73 @@ template <> struct FVec<1> { float v[1]; };
 template <> struct alignas(8) FVec<2> { float v[2]; };
 template <> struct alignas(16) FVec<4> { float v[4]; };
 
+// ---- float64 building blocks of the frequency pass ---------------------------------
+// The frequency pass is the float64 half of the path; its results are compared with
+// the CPU loop under the 1e-5 rel-L2 gate, not bit for bit (different libm exp,
+// different summation order of the deposit).  Inside that contract the two costly
+// IEEE operations are replaced by 1-2 ulp equivalents and FMA contraction is allowed.
+#pragma clang fp contract(fast)
+
+// exp(x), <= 2 ulp: x = (64 m + j) ln2/64 + r, |r| <= ln2/128;
+// exp(x) = 2^m * 2^(j/64) * (1 + r + ... + r^5/120)  (remainder r^6/720 < 4e-17).
+// tab[j] = 2^(j/64) lives in LDS.  Overflow -> inf, underflow -> 0, NaN -> NaN.
+__device__ __forceinline__ double exp_tab(double x, const double *tab)
+{
+    const double L2E64 = 92.33248261689366;         // 64 / ln 2
+    const double C_HI  = 0x1.62e42fef00000p-7;      // ln2/64, low 20 bits clear: t*C_HI exact
+    const double C_LO  = 0x1.473de6af278edp-40;
+    const double xc    = fmin(fmax(x, -1100.0), 1100.0);
+    const double t     = rint(xc * L2E64);
+    const int n        = (int) t;
+    double r           = fma(-t, C_HI, xc);
+    r                  = fma(-t, C_LO, r);
+    double p           = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p                  = fma(r, p, 1.0 / 6.0);
+    p                  = fma(r, p, 0.5);
+    p                  = fma(r, p, 1.0);
+    p                  = fma(r, p, 1.0);
+    return ldexp(tab[n & 63] * p, n >> 6); // a NaN argument is clamped away: callers that need it re-test
+}
+
+// a / b to ~1 ulp: hardware reciprocal, one Newton step, one residual correction
+__device__ __forceinline__ double div_fast(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    y        = fma(fma(-b, y, 1.0), y, y);
+    double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
+// Sum of v over the 64 lanes, valid in lane 63: four row_shr steps inside each row of
+// 16 lanes, then row_bcast:15 / row_bcast:31 across rows -- DPP moves (VALU latency)
+// instead of ds_bpermute round trips through the LDS crossbar.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_step(double v)
+{
+    const int lo  = __double2loint(v), hi = __double2hiint(v);
+    const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(thi, tlo);
+}
+__device__ __forceinline__ double wave_total_lane63(double v)
+{
+    v = dpp_step<0x111, 0xf>(v); // row_shr:1
+    v = dpp_step<0x112, 0xf>(v); // row_shr:2
+    v = dpp_step<0x114, 0xf>(v); // row_shr:4
+    v = dpp_step<0x118, 0xf>(v); // row_shr:8  -> lane 15 of each row holds the row sum
+    v = dpp_step<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_step<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    return v;
+}
+
 // Helper.h:549-557, one (sub-segment, frequency) update with emission
-__device__ __forceinline__ double ase_update(double Iv, float gs, float es, float w)
+__device__ __forceinline__ double ase_update(double Iv, float gs, float es, float w, const double *tab)
 {
     const double gl = (double) (gs * w); // f32 product, then widened (Helper.h:549-550)
     const double el = (double) (es * w);
     if (fabs(gl) < 1e-3)
         return el * (1.0 + 0.5 * gl * (1.0 + 0.3333333333 * gl)) + Iv * (1.0 + gl * (1.0 + 0.5 * gl));
-    const double eg = exp(gl);
-    return el / gl * (eg - 1.0) + Iv * eg;
+    const double eg = exp_tab(gl, tab);
+    return div_fast(el, gl) * (eg - 1.0) + Iv * eg;
 }
 
 // uniform-grid shortcut of deposit_index (RayTraceImageCPU.cpp:11-16): the grids
@@ -60,7 +118,8 @@ __device__ __forceinline__ int deposit_index_fast(int n, const double *g, double
 }
 
 template <int SF, int VEC>
-__device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const unsigned tile, const int lane)
+__device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const double *tab,
+                                          double *cache, const int nslot, const unsigned tile, const int lane)
 {
     const int S           = SF ? SF : P.L * RT_N_SUB;
     const int K           = P.K;
@@ -151,6 +210,32 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #pragma unroll
     for (int i = 0; i < 6; i++)
         addm[i] = (lane - (1 << i)) >= run_start;
+    // Few runs (ASE: a tile lies inside one pixel, or straddles two): one DPP wave sum
+    // per run and frequency, totals parked in lane (k mod 64) and flushed as ONE
+    // coalesced atomic per run and 64 frequencies.  Many runs (seeded): the segmented
+    // scan below.
+    constexpr int MAXQ               = 3;
+    const unsigned long long head_m  = __ballot(head);
+    const int n_runs                 = (int) __popcll(head_m);
+    const bool few                   = n_runs <= MAXQ;
+    // more runs than that (seeded mode: ~7 per tile): every run owns one row of the
+    // wave's LDS row cache [nslot][K]; lanes add into their run's row with LDS f64
+    // atomics, rows are flushed per tile with coalesced atomics.
+    const bool cached                = !few && n_runs <= nslot;
+    const unsigned long long le_mask = (lane == WAVE - 1) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+    const int run_id                 = (int) __popcll(head_m & le_mask) - 1;
+    int pixq[MAXQ];
+    double outq[MAXQ];
+    {
+        unsigned long long mm = head_m;
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int l = mm ? (int) __ffsll((long long) mm) - 1 : 0;
+            pixq[q]     = (mm && few) ? __builtin_amdgcn_readlane(pix, l) : -1;
+            outq[q]     = 0.0;
+            mm &= mm - 1;
+        }
+    }
 
     // ---- the march record of this lane's ray ---------------------------------------
     float gs[SF ? SF : 1], es[SF ? SF : 1];
@@ -177,7 +262,11 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                 FVec<VEC> w[SF ? SF : 1];
 #pragma unroll
                 for (int s = 0; s < SF; s++) {
+#ifdef RT_ABL_NOLOAD
+                    const float *row = P.gain[s / RT_N_SUB + 1].gv + kb;
+#else
                     const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) K + kb;
+#endif
                     w[s]             = *reinterpret_cast<const FVec<VEC> *>(row);
                 }
 #pragma unroll
@@ -185,7 +274,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     if (gs[s] != 0.0f || es[s] != 0.0f) { // else the update is the identity
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
-                            Iv[j] = ase_update(Iv[j], gs[s], es[s], w[s].v[j]);
+                            Iv[j] = ase_update(Iv[j], gs[s], es[s], w[s].v[j], tab);
                     }
                 }
             } else {
@@ -198,7 +287,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
-                            Iv[j] = ase_update(Iv[j], g1, e1, w.v[j]);
+                            Iv[j] = ase_update(Iv[j], g1, e1, w.v[j], tab);
                     }
                 }
             }
@@ -223,7 +312,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                 Iv[j] = f0 * P.seed.f[4][kb + j];
                 // 0 * exp(gl) is exactly 0 unless exp overflows: skip the exp then
                 if (f0 != 0.0 || gl[j] > 700.0)
-                    Iv[j] *= exp(gl[j]);
+                    Iv[j] *= (gl[j] != gl[j]) ? gl[j] : exp_tab(gl[j], tab);
             }
         }
 #pragma unroll
@@ -234,14 +323,56 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
             // RayTraceImageCPU.cpp:59, summed over the run of rays that share the pixel
             double v = pix >= 0 ? iv * P.scale : 0.0;
+            if (few) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const double t = __shfl_up(v, 1 << i, WAVE);
-                if (addm[i])
-                    v += t;
+                for (int q = 0; q < MAXQ; q++) {
+                    if (pixq[q] >= 0) {
+                        const double tot = wave_total_lane63(run_id == q ? v : 0.0);
+                        const double sum = readlane_f64(tot, WAVE - 1);
+                        if (lane == ((kb + j) & (WAVE - 1)))
+                            outq[q] += sum;
+                    }
+                }
+            } else if (cached) {
+                if (pix >= 0)
+                    unsafeAtomicAdd(&cache[run_id * K + kb + j], v);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double t = __shfl_up(v, 1 << i, WAVE);
+                    if (addm[i])
+                        v += t;
+                }
+                if (tail)
+                    unsafeAtomicAdd(&img_row[kb + j], v);
             }
-            if (tail)
-                unsafeAtomicAdd(&img_row[kb + j], v);
+        }
+        if (few && ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K)) {
+            // flush the window of 64 frequencies that ends here
+            const int kw = (kb + VEC - 1) & ~(WAVE - 1);
+            const int k  = kw + lane;
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) {
+                if (pixq[q] >= 0 && k < K)
+                    unsafeAtomicAdd(&P.image[(size_t) pixq[q] * (size_t) K + (size_t) k], outq[q]);
+                outq[q] = 0.0;
+            }
+        }
+    }
+    if (cached) {
+        // flush this tile's rows: one coalesced run of atomics per pixel run, rows re-zeroed
+        unsigned long long mm = head_m;
+        for (int q = 0; q < n_runs; q++) {
+            const int l  = (int) __ffsll((long long) mm) - 1;
+            const int pq = __builtin_amdgcn_readlane(pix, l);
+            mm &= mm - 1;
+            if (pq < 0)
+                continue;
+            for (int k = lane; k < K; k += WAVE) {
+                const double v = cache[q * K + k];
+                cache[q * K + k] = 0.0;
+                unsafeAtomicAdd(&P.image[(size_t) pq * (size_t) K + (size_t) k], v);
+            }
         }
     }
     if (live && (bad_neg || bad_nan)) {
@@ -259,16 +390,24 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 }
 
 template <int SF, int VEC>
-__global__ void __launch_bounds__(256) rt_freq_kernel(const DevParams P, const int iang_in_lds)
+__global__ void __launch_bounds__(256) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
 {
+    // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double exp2_tab[64]; // 2^(j/64), j = 0..63
     double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
     const int n_ang  = P.beam.na * P.beam.nb;
+    double *cache_wg = reinterpret_cast<double *>(lds_raw) + (iang_in_lds ? n_ang : 0);
+    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (size_t) nslot * (size_t) P.K;
+    for (int c = (int) threadIdx.x; c < 4 * nslot * P.K; c += (int) blockDim.x)
+        cache_wg[c] = 0.0;
+    if (threadIdx.x < 64)
+        exp2_tab[threadIdx.x] = exp2((double) threadIdx.x * (1.0 / 64.0));
     if (lds_iang) {
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x)
             lds_iang[c] = 0.0;
-        __syncthreads();
     }
+    __syncthreads();
     const int lane = lane_id();
     for (;;) {
         unsigned tile = 0;
@@ -277,7 +416,7 @@ __global__ void __launch_bounds__(256) rt_freq_kernel(const DevParams P, const i
         tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
         if (tile >= P.n_tiles)
             break;
-        freq_tile<SF, VEC>(P, lds_iang, tile, lane);
+        freq_tile<SF, VEC>(P, lds_iang, exp2_tab, cache, nslot, tile, lane);
     }
     if (lds_iang) {
         __syncthreads();

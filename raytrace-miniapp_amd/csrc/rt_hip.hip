@@ -100,7 +100,11 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
     const int in_lds       = ang_bytes <= 32 * 1024;
-    const size_t lds       = in_lds ? ang_bytes : 0;
+    // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K
+    // doubles, at most 10 KB per wave; fewer than 4 rows is not worth having
+    int nslot = (int) ((10 * 1024) / ((size_t) p->P.K * sizeof(double)));
+    nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
+    const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
     int per_cu             = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_freq_kernel<SF, VEC>, 256, lds));
     if (per_cu < 1)
@@ -111,7 +115,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         cap = cap_blocks;
     const unsigned grid = (unsigned) (want < cap ? want : cap);
     if (grid > 0) {
-        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, VEC>), dim3(grid), dim3(256), lds, stream, p->P, in_lds);
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, VEC>), dim3(grid), dim3(256), lds, stream, p->P, in_lds, nslot);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
