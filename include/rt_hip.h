@@ -156,6 +156,10 @@ int rt_hip_plan_fetch(rt_hip_plan *plan, double *image, double *I_ang,
  * the run's stream around the launch).  Waits for that run to finish. */
 int rt_hip_plan_kernel_ms(rt_hip_plan *plan, float *ms);
 
+/* The same, split by kernel: the march kernel (rt_march_kernel) and the frequency /
+ * deposit kernel (rt_freq_kernel) of the last run. */
+int rt_hip_plan_kernel_times(rt_hip_plan *plan, float *march_ms, float *freq_ms);
+
 /* Device pointers of the plan's own output buffers (for RCCL / torch views). */
 double *rt_hip_plan_image_ptr(rt_hip_plan *plan);
 double *rt_hip_plan_iang_ptr(rt_hip_plan *plan);

@@ -23,4 +23,4 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write
 echo "write done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o pmc -- $CMD > "$OUT/bench_sq.log" 2>&1 || echo "sq pass failed"
 echo "sq done"
-python3 profiles/summarize.py "$OUT" "$TAG"
+python3 profiles/summarize.py "$OUT" "$TAG" > "$OUT/summary.json"; tail -5 "$OUT/bench_trace.log"

@@ -3,9 +3,9 @@
 summaries that are committed under profiles/ (the raw CSVs stay in gpurun_out/).
 
   profiles/<tag>_kernel_stats.csv   per-kernel calls / total / avg ns (kernel-trace --stats)
-  profiles/<tag>_pmc.json           per-launch counter averages of rt_trace_kernel, with the
-                                    gfx950 FETCH_SIZE correction (x2, MI355X_MICROARCH.md HBM)
-  profiles/traffic_latest.json      {"hbm_bytes_per_launch": ...} read by bench.py
+  profiles/<tag>_pmc.json           per-launch counter averages of the path's kernels, with the
+                                    gfx950 FETCH_SIZE correction (x2, MI355X_MICROARCH.md "HBM")
+  profiles/traffic_latest.json      {"kernels": {kernel: hbm_bytes_per_launch}} read by bench.py
 """
 import csv
 import glob
@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-KERNEL = "rt_trace_kernel"
+KERNELS = ("rt_march_kernel", "rt_freq_kernel")
 
 
 def find(root, pattern):
@@ -22,58 +22,74 @@ def find(root, pattern):
     return hits[0] if hits else None
 
 
+def which(name):
+    for k in KERNELS:
+        if k in name:
+            return k
+    return None
+
+
 def kernel_stats(root, out_csv):
     f = find(Path(root) / "trace", "*kernel_stats.csv")
     if f is None:
-        return None
+        return {}
     rows = list(csv.DictReader(open(f)))
     with open(out_csv, "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=rows[0].keys())
         w.writeheader()
         w.writerows(rows)
+    out = {}
     for r in rows:
-        if KERNEL in r.get("Name", ""):
-            return {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
-                    "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
-    return None
+        k = which(r.get("Name", ""))
+        if k:
+            out[k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
+                      "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "percent": float(r["Percentage"])}
+    return out
 
 
 def pmc(root, sub):
     f = find(Path(root) / sub, "*counter_collection.csv")
+    out = {}
     if f is None:
-        return {}
-    acc = defaultdict(list)
+        return out
+    acc = defaultdict(lambda: defaultdict(list))
     meta = {}
     for r in csv.DictReader(open(f)):
-        if KERNEL not in r.get("Kernel_Name", ""):
+        k = which(r.get("Kernel_Name", ""))
+        if not k:
             continue
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size"):
-            if k in r:
-                meta[k] = r[k]
-    return {"avg": {k: sum(v) / len(v) for k, v in acc.items()}, "launches": {k: len(v) for k, v in acc.items()}, "meta": meta}
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = {m: r[m] for m in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                     "Grid_Size", "Workgroup_Size") if m in r}
+    for k, d in acc.items():
+        out[k] = {"avg": {c: sum(v) / len(v) for c, v in d.items()}, "launches": {c: len(v) for c, v in d.items()},
+                  "meta": meta[k]}
+    return out
 
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     here = Path(__file__).resolve().parent
-    ks = kernel_stats(root, here / f"{tag}_kernel_stats.csv")
-    out = {"tag": tag, "kernel": KERNEL, "kernel_trace": ks}
+    out = {"tag": tag, "kernels": list(KERNELS), "kernel_trace": kernel_stats(root, here / f"{tag}_kernel_stats.csv")}
     fetch, write, sq = pmc(root, "pmc_fetch"), pmc(root, "pmc_write"), pmc(root, "pmc_sq")
     out["pmc_fetch"], out["pmc_write"], out["pmc_sq"] = fetch, write, sq
-    hbm = None
-    if fetch.get("avg", {}).get("FETCH_SIZE") is not None and write.get("avg", {}).get("WRITE_SIZE") is not None:
-        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950 FETCH_SIZE counts half of the
+    hbm = {}
+    for k in KERNELS:
+        fs = fetch.get(k, {}).get("avg", {}).get("FETCH_SIZE")
+        ws = write.get(k, {}).get("avg", {}).get("WRITE_SIZE")
+        if fs is None or ws is None:
+            continue
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts half the
         # bytes of wide coalesced reads (MI355X_MICROARCH.md "HBM"): doubled here.  Narrow
-        # (4-8 B/lane) gathers are uncalibrated, so the read side is an upper bound.
-        rd = fetch["avg"]["FETCH_SIZE"] * 1024.0 * 2.0
-        wr = write["avg"]["WRITE_SIZE"] * 1024.0
-        hbm = rd + wr
-        out["hbm"] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": hbm,
-                      "note": "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024"}
+        # (4-16 B/lane) gathers are uncalibrated, so the read side is an upper bound.
+        rd, wr = fs * 1024.0 * 2.0, ws * 1024.0
+        hbm[k] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+    out["hbm"] = hbm
+    out["hbm_note"] = "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; separate --pmc passes"
     (here / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
-    if hbm is not None:
-        (here / "traffic_latest.json").write_text(json.dumps({"tag": tag, "hbm_bytes_per_launch": hbm, **out["hbm"]}, indent=1))
+    if hbm:
+        (here / "traffic_latest.json").write_text(json.dumps(
+            {"tag": tag, "kernels": {k: v["hbm_bytes_per_launch"] for k, v in hbm.items()}, "detail": hbm}, indent=1))
     print(json.dumps(out, indent=1))
 
 

@@ -138,6 +138,13 @@ class Plan:
         self.hl.check(self.hl.lib.rt_hip_plan_kernel_ms(self._h, C.byref(ms)), "rt_hip_plan_kernel_ms")
         return float(ms.value)
 
+    def kernel_times(self) -> tuple:
+        """(march_ms, freq_ms) of the last run (waits for it)."""
+        a, f = C.c_float(0), C.c_float(0)
+        self.hl.check(self.hl.lib.rt_hip_plan_kernel_times(self._h, C.byref(a), C.byref(f)),
+                      "rt_hip_plan_kernel_times")
+        return float(a.value), float(f.value)
+
     def fetch_probe(self) -> dict:
         n = self.n_rays
         S = (self.problem.N - 1) * cabi.RT_N_SUB

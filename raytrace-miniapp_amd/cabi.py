@@ -146,6 +146,8 @@ def declare_hip_api(lib: C.CDLL) -> None:
     lib.rt_hip_plan_fetch.restype = C.c_int
     lib.rt_hip_plan_kernel_ms.argtypes = [vp, P(C.c_float)]
     lib.rt_hip_plan_kernel_ms.restype = C.c_int
+    lib.rt_hip_plan_kernel_times.argtypes = [vp, P(C.c_float), P(C.c_float)]
+    lib.rt_hip_plan_kernel_times.restype = C.c_int
     lib.rt_hip_plan_image_ptr.argtypes = [vp]
     lib.rt_hip_plan_image_ptr.restype = vp
     lib.rt_hip_plan_iang_ptr.argtypes = [vp]
@@ -163,6 +165,6 @@ def declare_hip_api(lib: C.CDLL) -> None:
 HIP_API_SYMBOLS = [
     "rt_hip_device_count", "rt_hip_last_error", "rt_hip_image_loop", "rt_hip_plan_create",
     "rt_hip_plan_set_rays", "rt_hip_plan_set_ray_grid", "rt_hip_plan_run", "rt_hip_plan_fetch",
-    "rt_hip_plan_kernel_ms", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
+    "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
     "rt_hip_plan_fetch_probe", "rt_hip_plan_destroy",
 ]

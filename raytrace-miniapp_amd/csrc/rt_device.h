@@ -94,8 +94,8 @@ struct RecMeta {
 
 // Zeroed by a memset node before every run.
 struct DevCtl {
-    unsigned int next_tile;   // fused kernel: tile counter; march kernel: next ray
-    unsigned int next_tile_b; // frequency kernel: tile counter
+    unsigned int next_tile;   // march kernel: next unreserved ray index
+    unsigned int next_tile_b; // frequency kernel: next tile
     unsigned int failure_code;
     unsigned int n_failed;
     unsigned long long cell_steps;
@@ -129,8 +129,8 @@ struct DevParams {
     DevCtl *ctl;
     DevProbe probe;
     unsigned int n_tiles;
-    unsigned int debug; // bit0: skip phase B (profiling only, RT_HIP_DEBUG env)
-    // two-kernel path (rt_march.hip -> records -> rt_freq.hip)
+    unsigned int debug; // bit0: skip the frequency kernel (profiling only, RT_HIP_DEBUG env)
+    // rt_march.hip -> records -> rt_freq.hip
     const unsigned char *blob; // march blob (global copy)
     unsigned int blob_bytes;
     unsigned int pad2;

@@ -1,12 +1,12 @@
-// rt_hip.hip -- the C ABI of include/rt_hip.h on top of the HIP kernel.
+// rt_hip.hip -- the C ABI of include/rt_hip.h on top of the HIP kernels.
 //
 // Replaces the host side of RayTraceImageCudaLoop (src/RayTraceImageCuda.cu:145-221)
 // and of the copy_device helpers (src/RayTraceImageCuda.cu:224-329): where those
 // issue ~30 cudaMalloc/cudaMemcpy calls per create_image, a plan packs every
 // table into ONE arena, uploads it with ONE copy, zeroes outputs + control block
-// and launches ONE kernel.  Nothing is cached across calls (Readme.txt:43).
+// and launches the march kernel and the frequency kernel back to back on one
+// stream.  Nothing is cached across calls (Readme.txt:43).
 #include "rt_freq.hip"      // kernel B (includes rt_march.hip, kernel A)
-#include "rt_fused_v1.hip" // the round-1 fused kernel, kept selectable (RT_HIP_KERNEL=fused)
 
 #include <chrono>
 #include <cmath>
@@ -74,7 +74,6 @@ struct rt_hip_plan {
     float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
     unsigned char *rec = nullptr; // per-ray march records (two-kernel path)
     size_t rec_bytes   = 0;
-    bool fused         = false;   // RT_HIP_KERNEL=fused selects the round-1 fused kernel
     hipEvent_t evm     = nullptr; // between march and frequency kernels
     double *image_own  = nullptr;
     double *iang_own   = nullptr;
@@ -231,9 +230,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     if (beam->nx < 1 || beam->ny < 1 || beam->na < 1 || beam->nb < 1 || beam->nv < 1)
         return fail_arg("rt_hip_plan_create: empty beam grid");
     const int L = N - 1;
-    const size_t per_wave_lds = (size_t) L * RT_N_SUB * rt::WAVE * 12;
-    if (per_wave_lds > 64 * 1024)
-        return fail_arg("rt_hip_plan_create: too many lengths for the LDS record slab");
+    if (L > 64)
+        return fail_arg("rt_hip_plan_create: more than 65 lengths are not supported");
     const int K = beam->nv;
     for (int i = 1; i < N; i++) {
         if (gain[i].Nx < 2 || gain[i].Ny < 2 || !gain[i].x || !gain[i].y || !gain[i].n || !gain[i].g0 ||
@@ -434,8 +432,6 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipEventCreate(&p->evm));
-    if (const char *kname = getenv("RT_HIP_KERNEL"))
-        p->fused = strcmp(kname, "fused") == 0;
     P.rec_stride = (unsigned) align_up((size_t) L * RT_N_SUB * 12 + sizeof(rt::RecMeta), 16);
     P.ctl = p->ctl;
     *out  = p;
@@ -536,7 +532,6 @@ int rt_hip_plan_enable_probe(rt_hip_plan *p, int on)
 static int plan_prepare_probe(rt_hip_plan *p)
 {
     const size_t n = (size_t) p->n_rays;
-    const size_t S = (size_t) p->P.L * RT_N_SUB;
     if (!p->probe_on) {
         p->P.probe_on = 0;
         return RT_OK;
@@ -544,18 +539,15 @@ static int plan_prepare_probe(rt_hip_plan *p)
     if (p->probe_rays != n || !p->probe) {
         (void) hipFree(p->probe);
         p->probe = nullptr;
-        size_t bytes = n * S * 12 + n * (sizeof(rt_ray) + 8) + 1024;
+        size_t bytes = n * (sizeof(rt_ray) + 8) + 1024;
         HIP_TRY(hipMalloc((void **) &p->probe, bytes));
         p->probe_rays = n;
     }
     unsigned char *b = p->probe;
-    p->P.probe.gvl   = reinterpret_cast<float *>(b);
-    b += n * S * 4;
-    p->P.probe.evl = reinterpret_cast<float *>(b);
-    b += n * S * 4;
-    p->P.probe.ivl = reinterpret_cast<int32_t *>(b);
-    b += n * S * 4;
-    p->P.probe.ray2 = reinterpret_cast<rt_ray *>(b);
+    p->P.probe.gvl   = nullptr; // gvl / evl / ivl are read back from the march records
+    p->P.probe.evl   = nullptr;
+    p->P.probe.ivl   = nullptr;
+    p->P.probe.ray2  = reinterpret_cast<rt_ray *>(b);
     b += n * sizeof(rt_ray);
     p->P.probe.flags = reinterpret_cast<uint32_t *>(b);
     b += n * 4;
@@ -584,7 +576,7 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     if (rc != RT_OK)
         return rc;
     if (p->probe_on && p->n_rays)
-        HIP_TRY(hipMemsetAsync(p->probe, 0, (size_t) p->n_rays * ((size_t) p->P.L * RT_N_SUB * 12 + sizeof(rt_ray) + 8), stream));
+        HIP_TRY(hipMemsetAsync(p->probe, 0, (size_t) p->n_rays * (sizeof(rt_ray) + 8), stream));
     HIP_TRY(hipMemsetAsync(image_dev, 0, p->n_image * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(iang_dev, 0, p->n_iang * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(p->ctl, 0, sizeof(rt::DevCtl), stream));
@@ -592,36 +584,9 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     p->P.iang    = iang_dev;
     p->P.n_tiles = (unsigned) ((p->n_rays + rt::WAVE - 1) / rt::WAVE);
 
-    if (!p->fused) {
-        rc = plan_run_split(p, stream);
-        if (rc != RT_OK)
-            return rc;
-        p->last_stream = stream;
-        p->last_image  = image_dev;
-        p->last_iang   = iang_dev;
-        p->ran         = true;
-        return RT_OK;
-    }
-
-    // launch geometry: persistent waves, 1..4 waves per workgroup by LDS slab size
-    const size_t per_wave_lds = (size_t) p->P.L * RT_N_SUB * rt::WAVE * 12;
-    int waves                 = (int) ((48 * 1024) / per_wave_lds);
-    waves                     = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
-    const int block           = waves * rt::WAVE;
-    const size_t lds_bytes    = per_wave_lds * (size_t) waves;
-    int per_cu                = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_trace_kernel, block, lds_bytes));
-    if (per_cu < 1)
-        per_cu = 1;
-    unsigned long long want = ((unsigned long long) p->P.n_tiles + (unsigned) waves - 1) / (unsigned) waves;
-    unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
-    unsigned grid           = (unsigned) (want < cap ? want : cap);
-    HIP_TRY(hipEventRecord(p->ev0, stream));
-    if (grid > 0) {
-        hipLaunchKernelGGL(rt::rt_trace_kernel, dim3(grid), dim3((unsigned) block), lds_bytes, stream, p->P);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(p->ev1, stream));
+    rc = plan_run_split(p, stream);
+    if (rc != RT_OK)
+        return rc;
     p->last_stream = stream;
     p->last_image  = image_dev;
     p->last_iang   = iang_dev;
@@ -660,12 +625,8 @@ int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int
         float ms          = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
         stats->kernel_ms = ms;
-        stats->march_ms  = 0.0f;
-        stats->freq_ms   = 0.0f;
-        if (!p->fused) {
-            HIP_TRY(hipEventElapsedTime(&stats->march_ms, p->ev0, p->evm));
-            HIP_TRY(hipEventElapsedTime(&stats->freq_ms, p->evm, p->ev1));
-        }
+        HIP_TRY(hipEventElapsedTime(&stats->march_ms, p->ev0, p->evm));
+        HIP_TRY(hipEventElapsedTime(&stats->freq_ms, p->evm, p->ev1));
         stats->total_ms  = (float) std::chrono::duration<double, std::milli>(
                               std::chrono::steady_clock::now() - p->t_created).count();
     }
@@ -679,6 +640,17 @@ int rt_hip_plan_kernel_ms(rt_hip_plan *p, float *ms)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev1));
     HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return RT_OK;
+}
+
+int rt_hip_plan_kernel_times(rt_hip_plan *p, float *march_ms, float *freq_ms)
+{
+    if (!p || !p->ran || !march_ms || !freq_ms)
+        return fail_arg("rt_hip_plan_kernel_times: plan has not run");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    HIP_TRY(hipEventElapsedTime(march_ms, p->ev0, p->evm));
+    HIP_TRY(hipEventElapsedTime(freq_ms, p->evm, p->ev1));
     return RT_OK;
 }
 
@@ -705,7 +677,7 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->last_stream));
     const size_t n = (size_t) p->n_rays, S = (size_t) p->P.L * RT_N_SUB;
-    if (!p->fused) {
+    {
         // the march records themselves are the probe: de-interleave them
         std::vector<unsigned char> h(n * p->P.rec_stride);
         if (n)
@@ -719,16 +691,7 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
             if (ivl)
                 memcpy(ivl + r * S, rec + S * 8, S * 4);
         }
-        gvl = nullptr;
-        evl = nullptr;
-        ivl = nullptr;
     }
-    if (gvl)
-        HIP_TRY(hipMemcpy(gvl, p->P.probe.gvl, n * S * 4, hipMemcpyDeviceToHost));
-    if (evl)
-        HIP_TRY(hipMemcpy(evl, p->P.probe.evl, n * S * 4, hipMemcpyDeviceToHost));
-    if (ivl)
-        HIP_TRY(hipMemcpy(ivl, p->P.probe.ivl, n * S * 4, hipMemcpyDeviceToHost));
     if (ray2)
         HIP_TRY(hipMemcpy(ray2, p->P.probe.ray2, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
     if (flags)

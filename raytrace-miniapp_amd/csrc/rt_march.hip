@@ -240,9 +240,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 // [A1] end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0)
                 const int is   = backward ? RT_N_SUB - iz - 1 : iz;
                 const int slot = (ii - 1) * RT_N_SUB + is;
+#ifndef RT_ABL_NOSTORE
                 reinterpret_cast<float *>(rec)[slot]       = gacc;
                 reinterpret_cast<float *>(rec)[S + slot]   = eacc;
                 reinterpret_cast<int *>(rec)[2 * S + slot] = cell_last;
+#endif
                 any_nz    = any_nz | (gacc != 0.0f) | (eacc != 0.0f);
                 gacc      = 0.0f;
                 eacc      = 0.0f;

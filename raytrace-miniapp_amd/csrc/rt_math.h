@@ -1,7 +1,8 @@
 // rt_math.h -- device helpers shared by the kernels: wave utilities and the
-// float32/float64 building blocks of the march, each restating one helper of
-// src/common/RayTraceImageHelper.h with its promotions spelled out.  Compiled with
-// -ffp-contract=off: the march must take the reference's steps bit for bit.
+// float32/float64 building blocks shared by the march and frequency kernels, each
+// restating one helper of src/common/RayTraceImageHelper.h with its promotions
+// spelled out.  Compiled with -ffp-contract=off: the march must take the
+// reference's steps bit for bit.
 #pragma once
 
 #include "rt_device.h"
@@ -26,30 +27,13 @@ struct Inst {
     }
 };
 #define RT_TICK(i) inst.tick(i)
-#define RT_INST_ARG , Inst &inst
-#define RT_INST_PASS , inst
 #else
 #define RT_TICK(i)
-#define RT_INST_ARG
-#define RT_INST_PASS
 #endif
 
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & (WAVE - 1)); }
 
-__device__ __forceinline__ float sgpr_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, WAVE);
-    return v;
-}
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
 {
 #pragma unroll
@@ -121,38 +105,6 @@ __device__ __forceinline__ float lerp2(float u, float v, float f00, float f10, f
     return (u * f10 + u1 * f00) * v1 + (u * f11 + u1 * f01) * v;
 }
 
-// Helper.h:131-143.  The binary search returns the unique u in [1, n-1] with
-// (u == 1 || g[u-1] < v) && (u == n-1 || g[u] >= v) on a non-decreasing grid;
-// we guess u arithmetically (exact for the uniform grids the files hold),
-// repair by at most two neighbour moves and only then fall back to bisection.
-__device__ __forceinline__ uint32_t interval_index(const double *g, uint32_t n, double v, double inv_h)
-{
-    int last = (int) n - 1;
-    int u    = (int) ((v - g[0]) * inv_h) + 1;
-    u        = u < 1 ? 1 : (u > last ? last : u);
-    if (u > 1 && g[u - 1] >= v)
-        --u;
-    if (u > 1 && g[u - 1] >= v)
-        --u;
-    if (u < last && g[u] < v)
-        ++u;
-    if (u < last && g[u] < v)
-        ++u;
-    bool ok = (u == 1 || g[u - 1] < v) && (u == last || g[u] >= v);
-    if (!ok) {
-        uint32_t lo = 0, hi = n - 1;
-        while (hi - lo != 1) {
-            uint32_t mid = (hi + lo) / 2;
-            if (g[mid] >= v)
-                hi = mid;
-            else
-                lo = mid;
-        }
-        u = (int) hi;
-    }
-    return (uint32_t) u;
-}
-
 // Helper.h:101-117
 __device__ __forceinline__ int first_not_below(const double *g, int n, double v)
 {
@@ -169,88 +121,6 @@ __device__ __forceinline__ int first_not_below(const double *g, int n, double v)
             lo = mid;
     }
     return hi;
-}
-
-// RayTraceImageCPU.cpp:11-16
-__device__ __forceinline__ int deposit_index(int n, const double *g, double d, double v)
-{
-    if (v < g[0] - 0.5 * d || v > g[n - 1] + 0.5 * d)
-        return -1;
-    return first_not_below(g, n, v - 0.5 * d);
-}
-
-// Helper.h:270-313
-__device__ __forceinline__ float step_linear_medium(float &rx, float &ry, float &rz, float &sx, float &sy,
-                                                    float &sz, float n0, float gx, float gy, float lim0,
-                                                    float lim1, float lim2 RT_INST_ARG)
-{
-    const float c = 0.5f;
-    float path    = 0.0f;
-    float dzcap   = c * 1.00001f * lim2;
-    rx = 0.0f;
-    ry = 0.0f;
-    rz = 0.0f;
-    float n = n0;
-    while (fabsf(rx) < lim0 && fabsf(ry) < lim1 && fabsf(rz) < lim2 && (double) fabsf(n - n0) < 0.05) {
-        n        = n0 + rx * gx + ry * gy;
-        float t  = (sx * gx + sy * gy + 1e-12f) / n;
-        float fx = gx / n - sx * t;
-        float fy = gy / n - sy * t;
-        float fz = -sz * t;
-        float h  = c * 0.1f / fabsf(t);
-        h        = h < dzcap ? h : dzcap;
-        float h2 = 1.0001f * (lim2 - fabsf(rz)) / fabsf(sz);
-        float h3 = c * 0.05f * (fabsf(sx) + 5e-4f) / (fabsf(fx) + 1e-8f);
-        float h4 = c * 0.05f * (fabsf(sy) + 5e-4f) / (fabsf(fy) + 1e-8f);
-        h        = h < h2 ? h : h2;
-        h        = h < h3 ? h : h3;
-        h        = h < h4 ? h : h4;
-        float ht = h * t;
-        float c1 = 0.5f * h * h * (1.0f - ht / 3.0f + ht * ht / 12.0f);
-        rx += sx * h + c1 * fx;
-        ry += sy * h + c1 * fy;
-        rz += sz * h + c1 * fz;
-        float c2 = h * (1.0f - 0.5f * ht + ht * ht / 6.0f);
-        sx += c2 * fx;
-        sy += c2 * fy;
-        sz += c2 * fz;
-        renormalise(sx, sy, sz);
-        path += h;
-        RT_TICK(0);
-    }
-    return path;
-}
-
-// Helper.h:318-351
-__device__ __forceinline__ float cross_cell(float &px, float &py, float &pz, float &sx, float &sy, float &sz,
-                                            float dzrem, double xc0, double xc1, double yc0, double yc1,
-                                            float b0, float b1, float b2, float b3, double n00, double n10,
-                                            double n01, double n11, bool mirror_y RT_INST_ARG)
-{
-    float z        = 0.0f;
-    float path     = 0.0f;
-    const float wx = (float) (xc1 - xc0);
-    const float wy = (float) (yc1 - yc0);
-    float ya       = mirror_y ? fabsf(py) : py;
-    while (px > b0 && px < b1 && ya > b2 && ya < b3 && (double) z < 0.999 * (double) dzrem) {
-        ya       = mirror_y ? fabsf(py) : py;
-        float u  = (float) (((double) px - xc0) / (double) wx);
-        float v  = (float) (((double) ya - yc0) / (double) wy);
-        float n0 = lerp2(u, v, (float) n00, (float) n10, (float) n01, (float) n11);
-        float gx = (float) ((1.0 - (double) v) * (n10 - n00) / (double) wx + (double) v * (n11 - n01) / (double) wx);
-        float gy = (float) ((1.0 - (double) u) * (n01 - n00) / (double) wy + (double) u * (n11 - n10) / (double) wy);
-        if (mirror_y && py < 0)
-            gy = -gy;
-        float rx, ry, rz;
-        path += step_linear_medium(rx, ry, rz, sx, sy, sz, n0, gx, gy, 0.1f * wx, 0.1f * wy, dzrem - z RT_INST_PASS);
-        RT_TICK(1);
-        px += rx;
-        py += ry;
-        pz += rz;
-        z += fabsf(rz);
-        ya = mirror_y ? fabsf(py) : py;
-    }
-    return path;
 }
 
 // Helper.h:168-220

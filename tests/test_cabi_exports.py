@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_code_object_is_gfx950(lib):
     blob = lib.path.read_bytes()
-    assert b"gfx950" in blob and b"rt_trace_kernel" in blob
+    assert b"gfx950" in blob and b"rt_march_kernel" in blob and b"rt_freq_kernel" in blob
 
 
 def test_struct_layouts_match_the_header():
