@@ -137,6 +137,10 @@ struct DevParams {
     unsigned char *rec;
     unsigned int rec_stride;
     unsigned int chunk; // rays a wave reserves per fetch of the global ray counter
+    // 1: every pixel receives exactly one ray of this launch (ASE, ray grid == beam grid,
+    // na*nb == 1): the frequency kernel stores image rows instead of adding to them
+    unsigned int exclusive;
+    unsigned int pad3;
 };
 
 // flag bits of the per-ray march record

@@ -187,7 +187,16 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             P.ctl->failed[slot_f] = ray;
     }
     const bool live = have && !err1 && !(fl & F_SKIP);
-    if (__ballot(live) == 0ull)
+    // exclusive mode: this ray is the only contributor of pixel own_pix and must write its
+    // whole row (zeros if it contributes nothing); a ray that deposits elsewhere (never the
+    // case for a consistent grid) keeps the atomic path for the foreign pixel.
+    int own_pix = -1;
+    if (P.exclusive && have) {
+        const unsigned j = ridx % (unsigned) P.beam.ny, i = ridx / (unsigned) P.beam.ny;
+        own_pix          = (int) (i + j * (unsigned) P.beam.nx);
+    }
+    const bool excl_all = P.exclusive != 0;
+    if (__ballot(live) == 0ull && !excl_all)
         return;
     if (!live) {
         pix = -1;
@@ -323,7 +332,13 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
             // RayTraceImageCPU.cpp:59, summed over the run of rays that share the pixel
             double v = pix >= 0 ? iv * P.scale : 0.0;
-            if (few) {
+            if (excl_all) {
+                // one ray per pixel: plain stores of the row, no reduction, no atomics
+                if (own_pix >= 0)
+                    P.image[(size_t) own_pix * (size_t) K + (size_t) (kb + j)] = (pix == own_pix) ? v : 0.0;
+                if (pix >= 0 && pix != own_pix)
+                    unsafeAtomicAdd(&img_row[kb + j], v);
+            } else if (few) {
 #pragma unroll
                 for (int q = 0; q < MAXQ; q++) {
                     if (pixq[q] >= 0) {
@@ -347,7 +362,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     unsafeAtomicAdd(&img_row[kb + j], v);
             }
         }
-        if (few && ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K)) {
+        if (few && !excl_all && ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K)) {
             // flush the window of 64 frequencies that ends here
             const int kw = (kb + VEC - 1) & ~(WAVE - 1);
             const int k  = kw + lane;

@@ -72,6 +72,7 @@ struct rt_hip_plan {
     rt_ray *rays_dev   = nullptr;
     double *grid_dev   = nullptr; // ray grids when rays are generated
     float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
+    std::vector<double> beam_x, beam_y, beam_a, beam_b; // host copies, to recognise ray grid == beam grid
     unsigned char *rec = nullptr; // per-ray march records (two-kernel path)
     size_t rec_bytes   = 0;
     hipEvent_t evm     = nullptr; // between march and frequency kernels
@@ -426,6 +427,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     if (const char *dbg = getenv("RT_HIP_DEBUG"))
         P.debug = (unsigned) strtoul(dbg, nullptr, 0);
 
+    p->beam_x.assign(beam->x, beam->x + beam->nx);
+    p->beam_y.assign(beam->y, beam->y + beam->ny);
+    p->beam_a.assign(beam->a, beam->a + beam->na);
+    p->beam_b.assign(beam->b, beam->b + beam->nb);
     p->n_image = (size_t) beam->nx * (size_t) beam->ny * (size_t) beam->nv;
     p->n_iang  = (size_t) beam->na * (size_t) beam->nb;
     PLAN_TRY(hipMalloc((void **) &p->ctl, sizeof(rt::DevCtl)));
@@ -460,6 +465,7 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
+    p->P.exclusive  = 0;
     p->P.rays       = {};
     p->P.rays.list  = p->rays_dev;
     p->P.rays.sxy   = p->tan_dev;
@@ -518,6 +524,51 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     R.stride       = stride;
     R.count        = (unsigned long long) count;
     p->n_rays      = (unsigned long long) count;
+    // One ray per pixel, every pixel covered: in ASE mode ray ijkm lands in pixel (i, j)
+    // (SURVEY.md 8(c) i) -- the deposit index of the ray is verified per ray by the kernel,
+    // which falls back to atomics for any ray that does not land in its own pixel.
+    auto same = [](const std::vector<double> &v, const double *g, int n) {
+        return (int) v.size() == n && memcmp(v.data(), g, sizeof(double) * (size_t) n) == 0;
+    };
+    // RayTraceImageCPU.cpp:11-16 on the host: grid point i (rounded to float, as the ray
+    // carries it) must fall in deposit cell i
+    auto own_cell = [](const std::vector<double> &g, double d) {
+        const int n = (int) g.size();
+        for (int i = 0; i < n; i++) {
+            const double v = (double) (float) g[(size_t) i];
+            if (v < g[0] - 0.5 * d || v > g[(size_t) n - 1] + 0.5 * d)
+                return false;
+            const double t = v - 0.5 * d;
+            int idx        = 0;
+            if (t < g[0])
+                idx = 0;
+            else if (t > g[(size_t) n - 1])
+                idx = n;
+            else {
+                int lo = 0, hi = n - 1;
+                if (n == 1)
+                    hi = 1;
+                while (n > 1 && hi - lo != 1) {
+                    int mid = (hi + lo) / 2;
+                    if (g[(size_t) mid] >= t)
+                        hi = mid;
+                    else
+                        lo = mid;
+                }
+                idx = hi;
+            }
+            if (idx != i)
+                return false;
+        }
+        return true;
+    };
+    p->P.exclusive = (p->P.method == 1 && nga == 1 && ngb == 1 && first == 0 && stride == 1 && count == total &&
+                      same(p->beam_x, gx, ngx) && same(p->beam_y, gy, ngy) && same(p->beam_a, ga, nga) &&
+                      same(p->beam_b, gb, ngb) && own_cell(p->beam_x, p->P.beam.dx) &&
+                      own_cell(p->beam_y, p->P.beam.dy) && own_cell(p->beam_a, p->P.beam.da) &&
+                      own_cell(p->beam_b, p->P.beam.db))
+                         ? 1u
+                         : 0u;
     return RT_OK;
 }
 
@@ -577,7 +628,8 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
         return rc;
     if (p->probe_on && p->n_rays)
         HIP_TRY(hipMemsetAsync(p->probe, 0, (size_t) p->n_rays * (sizeof(rt_ray) + 8), stream));
-    HIP_TRY(hipMemsetAsync(image_dev, 0, p->n_image * sizeof(double), stream));
+    if (!p->P.exclusive) // exclusive mode writes every image row exactly once
+        HIP_TRY(hipMemsetAsync(image_dev, 0, p->n_image * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(iang_dev, 0, p->n_iang * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(p->ctl, 0, sizeof(rt::DevCtl), stream));
     p->P.image   = image_dev;

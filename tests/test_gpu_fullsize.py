@@ -54,3 +54,20 @@ def test_synthetic_config5_tile_vs_oracle(hip, oracle, ase_small):
     assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
     assert rel_l2(out["image"], ref["image"]) < TOL and rel_l2(out["I_ang"], ref["I_ang"]) < TOL
     assert np.linalg.norm(ref["image"]) > 0
+
+
+def test_exclusive_pixel_mode_equals_atomic_mode(hip, oracle, ase_small):
+    """na = nb = 1 on the beam's own grid: one ray per pixel, rows are stored, not added.
+    Same image as the oracle, and as the list path (which never uses the store mode)."""
+    p = problem_mod.resample_frequency(ase_small, 128)
+    p = problem_mod.regrid_beam(p, nx=70, ny=33, a_centre=-1.0, b_centre=-4.5)
+    with hip.Plan(p) as plan:
+        a = plan.set_ray_grid().run().fetch()
+        a2 = plan.run().fetch()                      # re-run: rows are rewritten, not accumulated
+    with hip.Plan(p) as plan:
+        b = plan.set_rays(p.build_rays()).run().fetch()
+    ref = oracle.image_loop(p, n_threads=4)
+    assert np.array_equal(a["image"], a2["image"])
+    assert rel_l2(a["image"], ref["image"]) < 1e-11 and rel_l2(b["image"], ref["image"]) < 1e-11
+    assert rel_l2(a["I_ang"], ref["I_ang"]) < 1e-11
+    assert (a["image"] == 0).reshape(-1, 128).all(axis=1).sum() == (ref["image"] == 0).reshape(-1, 128).all(axis=1).sum()
