@@ -1,18 +1,16 @@
 // rt_device.h -- device-side records of the HIP ray-trace backend (gfx950).
 //
 // Layout in HBM (one arena per plan, packed by rt_hip_plan_create):
-//   per length ii = 1..N-1 (gain[0] is never read on the path except for the
-//   E0 != NULL test, src/common/RayTraceImageHelper.h:402,435-441):
-//     x[Nx], y[Ny]            double   grid coordinates
-//     node[Nx*Ny]             16 B     {double n; float g0; float E0}: the three
-//                                      quantities a cell-step gathers at each of
-//                                      the 4 cell corners (Helper.h:474-489)
-//                                      fused into one record, so a cell-step is
-//                                      two 32-byte reads (corner pairs are adjacent)
-//     gv[Nx*Ny][K]            float    lineshape rows, k fastest (coalesced row read
-//                                      with lanes = frequencies)
-//   beam grids x,y,a,b,dv (double), seed tables (double), the ray list (16 B/ray)
-//   when rays are given explicitly.
+//   march blob (BlobGain below): per length ii = 1..N-1 (gain[0] is never read on the
+//     path except for the E0 != NULL test, src/common/RayTraceImageHelper.h:402,435-441)
+//     x[Nx], y[Ny] (f64), reciprocal pairs per grid interval, and
+//     node[Nx*Ny] = {double n; float g0; float E0}: the three quantities a cell-step
+//     gathers at each of the 4 cell corners (Helper.h:474-489) fused into one 16-byte
+//     record (corner pairs are adjacent).  Copied into LDS by the march kernel.
+//   gv[Nx*Ny][K] float per length: lineshape rows, k fastest (frequency kernel)
+//   beam grids x,y,a,b,dv (double), seed tables (double), tangent tables,
+//   the ray list (16 B/ray) when rays are given explicitly,
+//   march records (96 B/ray for N = 3) between the two kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,16 +26,10 @@ struct alignas(16) Node {
     float E0;
 };
 
+// Per-length table that stays in HBM/L2: the lineshape rows read by the frequency kernel.
+// (Everything the march reads lives in the march blob below.)
 struct DevGain {
-    const double *x;
-    const double *y;
-    const Node *node;
-    const float *gv;
-    int Nx, Ny;
-    float lo_x, hi_x, lo_y, hi_y; // plasma box as floats (Helper.h:445-453)
-    int mirror_y;
-    int pad;
-    double inv_hx, inv_hy; // (Nx-1)/(x[Nx-1]-x[0]): index guess for uniform grids
+    const float *gv; // [Nx*Ny][K], k fastest
 };
 
 // Header of one length inside the "march blob": everything the march gathers, laid
@@ -105,10 +97,8 @@ struct DevCtl {
     rt_ray failed[RT_N_FAILED_MAX];
 };
 
+// probe outputs of the frequency kernel (gvl / evl / ivl are read back from the records)
 struct DevProbe {
-    float *gvl;
-    float *evl;
-    int32_t *ivl;
     rt_ray *ray2;
     uint32_t *flags;
     uint32_t *steps;

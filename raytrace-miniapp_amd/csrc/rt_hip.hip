@@ -264,43 +264,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     // ---- pack the arena -------------------------------------------------
     ArenaBuilder ab;
     std::vector<rt::DevGain> dg((size_t) N);
-    struct GOff {
-        size_t x, y, node, gv;
-    };
-    std::vector<GOff> goff((size_t) N);
+    std::vector<size_t> off_gv((size_t) N, 0);
     const bool use_emis = gain[0].E0 != nullptr && seed == nullptr; // Helper.h:402
-    for (int i = 1; i < N; i++) {
-        const rt_gain &g  = gain[i];
-        const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
-        goff[i].x         = ab.put(g.x, sizeof(double) * (size_t) g.Nx);
-        goff[i].y         = ab.put(g.y, sizeof(double) * (size_t) g.Ny);
-        goff[i].node      = ab.reserve(sizeof(rt::Node) * npix);
-        rt::Node *nd      = reinterpret_cast<rt::Node *>(ab.host.data() + goff[i].node);
-        for (size_t c = 0; c < npix; c++) {
-            nd[c].n  = g.n[c];
-            nd[c].g0 = g.g0[c];
-            nd[c].E0 = g.E0 ? g.E0[c] : 0.0f;
-        }
-        goff[i].gv = ab.put(g.gv, sizeof(float) * npix * (size_t) K);
-        rt::DevGain &d = dg[(size_t) i];
-        d.Nx           = g.Nx;
-        d.Ny           = g.Ny;
-        d.lo_x         = (float) g.x[0];
-        d.hi_x         = (float) g.x[g.Nx - 1];
-        d.lo_y         = (float) g.y[0];
-        d.hi_y         = (float) g.y[g.Ny - 1];
-        d.mirror_y     = 0;
-        if (d.lo_y >= 0) { // Helper.h:449-453
-            d.lo_y     = -d.hi_y;
-            d.mirror_y = 1;
-        }
-        d.inv_hx = (double) (g.Nx - 1) / (g.x[g.Nx - 1] - g.x[0]);
-        d.inv_hy = (double) (g.Ny - 1) / (g.y[g.Ny - 1] - g.y[0]);
-        if (!std::isfinite(d.inv_hx))
-            d.inv_hx = 0.0;
-        if (!std::isfinite(d.inv_hy))
-            d.inv_hy = 0.0;
-    }
+    for (int i = 1; i < N; i++)
+        off_gv[(size_t) i] = ab.put(gain[i].gv, sizeof(float) * (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K);
     const size_t off_bx  = ab.put(beam->x, sizeof(double) * (size_t) beam->nx);
     const size_t off_by  = ab.put(beam->y, sizeof(double) * (size_t) beam->ny);
     const size_t off_ba  = ab.put(beam->a, sizeof(double) * (size_t) beam->na);
@@ -330,17 +297,25 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
         rt::BlobGain h;
         memset(&h, 0, sizeof(h));
-        h.lo_x     = dg[(size_t) i].lo_x;
-        h.hi_x     = dg[(size_t) i].hi_x;
-        h.lo_y     = dg[(size_t) i].lo_y;
-        h.hi_y     = dg[(size_t) i].hi_y;
-        h.Nx       = g.Nx;
-        h.Ny       = g.Ny;
-        h.mirror_y = dg[(size_t) i].mirror_y;
-        h.x0       = g.x[0];
-        h.y0       = g.y[0];
-        h.inv_hx   = dg[(size_t) i].inv_hx;
-        h.inv_hy   = dg[(size_t) i].inv_hy;
+        h.lo_x     = (float) g.x[0]; // Helper.h:445-448
+        h.hi_x     = (float) g.x[g.Nx - 1];
+        h.lo_y     = (float) g.y[0];
+        h.hi_y     = (float) g.y[g.Ny - 1];
+        h.mirror_y = 0;
+        if (h.lo_y >= 0) { // Helper.h:449-453
+            h.lo_y     = -h.hi_y;
+            h.mirror_y = 1;
+        }
+        h.Nx     = g.Nx;
+        h.Ny     = g.Ny;
+        h.x0     = g.x[0];
+        h.y0     = g.y[0];
+        h.inv_hx = (double) (g.Nx - 1) / (g.x[g.Nx - 1] - g.x[0]);
+        h.inv_hy = (double) (g.Ny - 1) / (g.y[g.Ny - 1] - g.y[0]);
+        if (!std::isfinite(h.inv_hx))
+            h.inv_hx = 0.0;
+        if (!std::isfinite(h.inv_hy))
+            h.inv_hy = 0.0;
         h.off_x    = (int) blob.size();
         blob.resize(align_up(blob.size() + sizeof(double) * (size_t) g.Nx, 16));
         memcpy(blob.data() + h.off_x, g.x, sizeof(double) * (size_t) g.Nx);
@@ -364,7 +339,12 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         h.off_ry   = put_recips(g.y, g.Ny);
         h.off_node = (int) blob.size();
         blob.resize(blob.size() + sizeof(rt::Node) * npix);
-        memcpy(blob.data() + h.off_node, ab.host.data() + goff[i].node, sizeof(rt::Node) * npix);
+        rt::Node *nd = reinterpret_cast<rt::Node *>(blob.data() + h.off_node);
+        for (size_t c = 0; c < npix; c++) { // the three gathered quantities fused per grid point
+            nd[c].n  = g.n[c];
+            nd[c].g0 = g.g0[c];
+            nd[c].E0 = g.E0 ? g.E0[c] : 0.0f;
+        }
         memcpy(blob.data() + sizeof(rt::BlobGain) * (size_t) i, &h, sizeof(h));
     }
     const size_t off_blob = ab.put(blob.data(), blob.size());
@@ -382,10 +362,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     PLAN_TRY(hipMalloc((void **) &p->arena, p->arena_bytes));
     unsigned char *A = p->arena;
     for (int i = 1; i < N; i++) {
-        dg[(size_t) i].x    = reinterpret_cast<const double *>(A + goff[i].x);
-        dg[(size_t) i].y    = reinterpret_cast<const double *>(A + goff[i].y);
-        dg[(size_t) i].node = reinterpret_cast<const rt::Node *>(A + goff[i].node);
-        dg[(size_t) i].gv   = reinterpret_cast<const float *>(A + goff[i].gv);
+        dg[(size_t) i].gv = reinterpret_cast<const float *>(A + off_gv[(size_t) i]);
     }
     memcpy(ab.host.data() + off_gain, dg.data(), sizeof(rt::DevGain) * (size_t) N);
     PLAN_TRY(hipMemcpy(p->arena, ab.host.data(), ab.host.size(), hipMemcpyHostToDevice));
@@ -595,9 +572,6 @@ static int plan_prepare_probe(rt_hip_plan *p)
         p->probe_rays = n;
     }
     unsigned char *b = p->probe;
-    p->P.probe.gvl   = nullptr; // gvl / evl / ivl are read back from the march records
-    p->P.probe.evl   = nullptr;
-    p->P.probe.ivl   = nullptr;
     p->P.probe.ray2  = reinterpret_cast<rt_ray *>(b);
     b += n * sizeof(rt_ray);
     p->P.probe.flags = reinterpret_cast<uint32_t *>(b);

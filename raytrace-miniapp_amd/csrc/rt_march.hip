@@ -146,8 +146,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     unsigned steps = 0;
     bool escaped = false, any_nz = false, mirror = false;
     // cell (corner values are re-read from the blob in block [B])
-    int k1 = 1, k2 = 1, c00 = 0;
-    double rwx = 1, rwy = 1; // 1/(double)wx, 1/(double)wy of the current cell
+    int c00 = 0, node_off = 0, row_bytes = 0; // corner node (index, blob byte offset), bytes per grid row
+    double xc0 = 0, yc0 = 0;  // lower-left corner coordinates of the current cell
+    double rwx = 1, rwy = 1;  // 1/(double)wx, 1/(double)wy of the current cell
     float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
     float dzrem = 0, zc = 0, path = 0;
     // integrator
@@ -278,7 +279,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             if ((st == ST_CELL) & in_seg) {
                 // [A2] escape test + cell setup (Helper.h:465-497)
                 const BlobGain G = hdr[ii];
-                if ((px < G.lo_x) | (px > G.hi_x) | (py < G.lo_y) | (py > G.hi_y) | ((double) (sz * sz) < 0.01)) {
+                // (double)(sz*sz) < 0.01 (Helper.h:466) <=> sz*sz <= 0.01f: 0.01f is the largest float below 0.01
+                if ((px < G.lo_x) | (px > G.hi_x) | (py < G.lo_y) | (py > G.hi_y) | (sz * sz <= 0.01f)) {
                     escaped = true; // its slot is committed by [A1] next iteration
                 } else {
                     mirror           = G.mirror_y != 0;
@@ -286,10 +288,12 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     const double *gy = reinterpret_cast<const double *>(tab + G.off_y);
                     const Node *node = reinterpret_cast<const Node *>(tab + G.off_node);
                     const float ya   = mirror ? fabsf(py) : py;
-                    double xc0, xc1, yc0, yc1;
-                    k1  = (int) find_interval(gx, G.Nx, G.x0, G.inv_hx, (double) px, xc0, xc1);
-                    k2  = (int) find_interval(gy, G.Ny, G.y0, G.inv_hy, (double) ya, yc0, yc1);
-                    c00 = (k1 - 1) + (k2 - 1) * G.Nx;
+                    double xc1, yc1;
+                    const int k1 = (int) find_interval(gx, G.Nx, G.x0, G.inv_hx, (double) px, xc0, xc1);
+                    const int k2 = (int) find_interval(gy, G.Ny, G.y0, G.inv_hy, (double) ya, yc0, yc1);
+                    c00          = (k1 - 1) + (k2 - 1) * G.Nx;
+                    node_off     = G.off_node + c00 * (int) sizeof(Node);
+                    row_bytes    = G.Nx * (int) sizeof(Node);
                     const Node a00 = node[c00], a10 = node[c00 + 1];
                     const Node a01 = node[c00 + G.Nx], a11 = node[c00 + G.Nx + 1];
                     const double hx = xc1 - xc0, hy = yc1 - yc0;
@@ -355,12 +359,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
-            const BlobGain G = hdr[ii];
-            const double xc0 = reinterpret_cast<const double *>(tab + G.off_x)[k1 - 1];
-            const double yc0 = reinterpret_cast<const double *>(tab + G.off_y)[k2 - 1];
-            const Node *node = reinterpret_cast<const Node *>(tab + G.off_node);
-            const double n00 = node[c00].n, n10 = node[c00 + 1].n;
-            const double n01 = node[c00 + G.Nx].n, n11 = node[c00 + G.Nx + 1].n;
+            const double n00 = *reinterpret_cast<const double *>(tab + node_off);
+            const double n10 = *reinterpret_cast<const double *>(tab + node_off + (int) sizeof(Node));
+            const double n01 = *reinterpret_cast<const double *>(tab + node_off + row_bytes);
+            const double n11 = *reinterpret_cast<const double *>(tab + node_off + row_bytes + (int) sizeof(Node));
             const float ya   = mirror ? fabsf(py) : py;
             const double dwx = (double) wx, dwy = (double) wy;
             const float u    = (float) div_by_recip((double) px - xc0, dwx, rwx);
@@ -387,7 +389,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         if (st == ST_STEP) {
             const float c    = 0.5f;
             const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
-            bool run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & ((double) fabsf(n - n0) < 0.05);
+            // (double)|n - n0| < 0.05 (Helper.h:280) <=> |n - n0| < 0.05f: 0.05f is the smallest float above 0.05
+            bool run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & (fabsf(n - n0) < 0.05f);
             if (run) {
                 n        = n0 + rx * gxn + ry * gyn;
                 const float rn = 1.0f / n; // one IEEE division, three exact quotients
@@ -416,7 +419,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 renormalise(sx, sy, sz);
                 hsum += h;
                 RT_TICK(0);
-                run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & ((double) fabsf(n - n0) < 0.05);
+                run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & (fabsf(n - n0) < 0.05f);
             }
             if (!run) {
                 // integrator loop over: close this cross-cell iteration (Helper.h:343-348)

@@ -78,7 +78,7 @@ __device__ __forceinline__ float div_by_recip(float a, float b, float y)
     const float r = fmaf(-b, q, a);
     float c       = fmaf(r, y, q);
     c             = (r == 0.0f) ? q : c;
-    if (fabsf(a) < 1e-30f && a != 0.0f) {
+    if (fabsf(a) < 1e-29f && a != 0.0f) { // the residual must stay a normal float: |a| > 2^-102 (CPU test: none above 3e-32)
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
         c = a / b;
     }
@@ -90,7 +90,7 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
     const double r = fma(-b, q, a);
     double c       = fma(r, y, q);
     c              = (r == 0.0) ? q : c;
-    if (fabs(a) < 1e-290 && a != 0.0) {
+    if (fabs(a) < 1e-280 && a != 0.0) { // residual normal: |a| > 2^-969
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
         c = a / b;
     }

@@ -42,9 +42,9 @@ static inline uint32_t bf(float f){uint32_t u; memcpy(&u,&f,4); return u;}
 static inline uint64_t bd(double f){uint64_t u; memcpy(&u,&f,8); return u;}
 /* raytrace-miniapp_amd/csrc/rt_math.h, div_by_recip, restated for the host */
 static inline float d32(float a, float b, float y){ float q=a*y, r=fmaf(-b,q,a), c=fmaf(r,y,q); c=(r==0.0f)?q:c;
-    if (fabsf(a) < 1e-30f && a != 0.0f) c = a/b; return c; }
+    if (fabsf(a) < 1e-29f && a != 0.0f) c = a/b; return c; }
 static inline double d64(double a, double b, double y){ double q=a*y, r=fma(-b,q,a), c=fma(r,y,q); c=(r==0.0)?q:c;
-    if (fabs(a) < 1e-290 && a != 0.0) c = a/b; return c; }
+    if (fabs(a) < 1e-280 && a != 0.0) c = a/b; return c; }
 static uint64_t s = 88172645463325252ULL;
 static inline uint64_t xr(void){ s^=s<<13; s^=s>>7; s^=s<<17; return s; }
 /* returns the number of mismatches against IEEE division */
@@ -99,3 +99,18 @@ def test_division_by_correctly_rounded_reciprocal_is_ieee_division(tmp_path):
     lib.check.restype = ctypes.c_long
     lib.check.argtypes = [ctypes.c_long, ctypes.c_uint32]
     assert lib.check(20_000_000, 97) == 0
+
+
+def test_float_thresholds_equal_the_double_comparisons():
+    """rt_march.hip compares in float where the reference compares a widened float with
+    a double literal: (double)x < 0.05 <=> x < 0.05f (Helper.h:280) and
+    (double)x < 0.01 <=> x <= 0.01f (Helper.h:466, :515).  Comparisons are monotone in x,
+    so checking the floats around each literal is exhaustive."""
+    for lit, as_float, op in ((0.05, np.float32(0.05), np.less), (0.01, np.float32(0.01), np.less_equal)):
+        centre = as_float.view(np.uint32)
+        x = np.arange(int(centre) - 1000, int(centre) + 1000, dtype=np.uint32).view(np.float32)
+        x = np.concatenate([x, np.float32([0.0, 1e-30, 1.0, np.inf])])
+        want = x.astype(np.float64) < lit
+        got = op(x, as_float)
+        assert np.array_equal(want, got)
+    assert float(np.float32(0.05)) > 0.05 and float(np.float32(0.01)) < 0.01
