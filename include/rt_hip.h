@@ -173,6 +173,18 @@ int rt_hip_plan_enable_probe(rt_hip_plan *plan, int on);
 int rt_hip_plan_fetch_probe(rt_hip_plan *plan, float *gvl, float *evl, int32_t *ivl,
                             rt_ray *ray2, uint32_t *flags, uint32_t *steps);
 
+/* Step safety factor c of the integrator (`c` of RayTrace_calc_ray, Helper.h:381;
+ * create_image always uses 0.5, RayTrace::calc_ray_path passes its own).  0 < c < 1. */
+int rt_hip_plan_set_step_factor(rt_hip_plan *plan, double c);
+
+/* Path tracer, replaces RayTrace::calc_ray_path (src/RayTraceImage.cpp:440-477): with it
+ * enabled a run produces, instead of the image, for every ray the {x, y, I} triples at
+ * the 3 (N-1) + 1 sub-segment boundaries -- exactly the `debug` array of
+ * RayTrace_calc_ray (Helper.h:419-426, 505-511, 536-542, 559-566) -- and the ray's
+ * return code (0, -1, -2, -3).  path: [n_rays][3 (N-1) + 1][3] floats, err: [n_rays]. */
+int rt_hip_plan_enable_path(rt_hip_plan *plan, int on);
+int rt_hip_plan_fetch_path(rt_hip_plan *plan, float *path, int32_t *err);
+
 void rt_hip_plan_destroy(rt_hip_plan *plan);
 
 #ifdef __cplusplus

@@ -54,6 +54,10 @@ class Oracle:
             C.c_size_t, cabi.c_float_p, cabi.c_float_p, P(C.c_int32), P(cabi.RtRay),
             P(C.c_uint32), P(C.c_uint32), cabi.c_double_p, P(C.c_int32)]
         L.rt_oracle_probe.restype = C.c_int
+        L.rt_oracle_calc_ray_path.argtypes = [
+            C.c_int, P(cabi.RtBeam), P(cabi.RtGain), P(cabi.RtSeed), C.c_int, C.c_float, P(cabi.RtRay),
+            C.c_size_t, cabi.c_float_p, P(C.c_int32)]
+        L.rt_oracle_calc_ray_path.restype = C.c_int
 
     def image_loop(self, problem, rays=None, n_threads: int = 1):
         """Returns dict(image, I_ang, failure_code, failed_rays, counters, seconds)."""
@@ -101,6 +105,21 @@ class Oracle:
         return out
 
 
+    def calc_ray_path(self, problem, rays, c: float = 0.5):
+        """Per ray: x, y, I at the 3(N-1)+1 sub-segment boundaries -> dict(x, y, I [n][N2], err)."""
+        m = cabi.Marshalled(problem)
+        n = len(rays)
+        N2 = (problem.N - 1) * cabi.RT_N_SUB + 1
+        path = np.zeros((n, N2, 3), np.float32)
+        err = np.zeros(n, np.int32)
+        rc = self.lib.rt_oracle_calc_ray_path(m.N, C.byref(m.beam), m.gain, m.seed_ref, problem.method, c,
+                                              cabi.rays_ptr(rays), n, cabi._fp(path),
+                                              err.ctypes.data_as(P(C.c_int32)))
+        if rc != 0:
+            raise RuntimeError("rt_oracle_calc_ray_path failed")
+        return dict(x=path[:, :, 0].copy(), y=path[:, :, 1].copy(), I=path[:, :, 2].copy(), err=err)
+
+
 class Reference:
     """The compiled, unmodified reference CPU path (None-safe: `available()`)."""
 
@@ -128,6 +147,9 @@ class Reference:
         L.ref_calc_rays_file.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, cabi.c_double_p,
                                          cabi.c_double_p, P(C.c_int), cabi.c_double_p]
         L.ref_calc_rays_file.restype = C.c_int
+        L.ref_calc_ray_path_file.argtypes = [C.c_char_p, P(C.c_int), P(C.c_int), C.c_double, cabi.c_float_p,
+                                             cabi.c_float_p, cabi.c_float_p]
+        L.ref_calc_ray_path_file.restype = C.c_int
 
     def cpu_loop(self, problem, rays=None):
         m = cabi.Marshalled(problem)
@@ -167,6 +189,21 @@ class Reference:
             raise RuntimeError("ref_create_image_file failed")
         return dict(image=image, I_ang=iang, golden_image=gimg, golden_I_ang=gang,
                     seconds=sec.value, dims=d)
+
+    def calc_ray_path_file(self, path, i0, n, c: float = 0.5):
+        """RayTrace::calc_ray_path on the sub-grid [i0, i0+n) of the file's ray grid.
+        Returns x, y, I as [nb][na][ny][nx][N2] arrays (the reference's layout) and the error count."""
+        d = self.file_dims(path)
+        N2 = (d["N"] - 1) * cabi.RT_N_SUB + 1
+        tot = N2 * n[0] * n[1] * n[2] * n[3]
+        xr, yr, ir = (np.zeros(tot, np.float32) for _ in range(3))
+        a0 = (C.c_int * 4)(*i0)
+        an = (C.c_int * 4)(*n)
+        nerr = self.lib.ref_calc_ray_path_file(str(path).encode(), a0, an, c, cabi._fp(xr), cabi._fp(yr), cabi._fp(ir))
+        if nerr < 0:
+            raise RuntimeError("ref_calc_ray_path_file failed")
+        shp = (n[3], n[2], n[1], n[0], N2)
+        return dict(x=xr.reshape(shp), y=yr.reshape(shp), I=ir.reshape(shp), n_errors=nerr)
 
     def calc_rays_file(self, path, stride: int, n: int):
         d = self.file_dims(path)

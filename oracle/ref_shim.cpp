@@ -246,4 +246,32 @@ int ref_calc_rays_file(const char *path, size_t stride, size_t n, double *Iv_out
     return 0;
 }
 
+/* RayTrace::calc_ray_path (src/RayTraceImage.cpp:440-477) on a sub-grid of the file's own
+ * ray grid: n[4] points starting at i0[4] along x, y, a, b.  xr/yr/Ir: the reference's
+ * layout, N2 * (i + j*nx + k*nx*ny + m*nx*ny*na) + step.  Returns the error count. */
+int ref_calc_ray_path_file(const char *path, const int *i0, const int *n, double c, float *xr, float *yr,
+                           float *Ir)
+{
+    RayTrace::create_image_struct *info = load_file(path);
+    if (!info)
+        return -1;
+    const RayTrace::EUV_beam_struct *eb = info->euv_beam;
+    const double *g[4] = { eb->x, eb->y, eb->a, eb->b };
+    int method         = 1;
+    if (info->seed != NULL) {
+        method = 2;
+        g[0] = info->seed_beam->x; g[1] = info->seed_beam->y;
+        g[2] = info->seed_beam->a; g[3] = info->seed_beam->b;
+    }
+    std::vector<float> vx, vy, vi;
+    int nerr = RayTrace::calc_ray_path(n[0], n[1], n[2], n[3], g[0] + i0[0], g[1] + i0[1], g[2] + i0[2],
+                                       g[3] + i0[3], info->N, eb->dz, info->gain, info->seed, eb->nv, eb->dv,
+                                       method, c, vx, vy, vi);
+    memcpy(xr, vx.data(), vx.size() * sizeof(float));
+    memcpy(yr, vy.data(), vy.size() * sizeof(float));
+    memcpy(Ir, vi.data(), vi.size() * sizeof(float));
+    free_info(info);
+    return nerr;
+}
+
 } // extern "C"

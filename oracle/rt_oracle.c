@@ -236,9 +236,9 @@ static float cross_cell(vec3f *pos, vec3f *s, float dzrem, const double xc[2], c
  * gvl/evl/ivl [L][3] (L = N-1), the exit ray and flags.
  * Returns 0, or -1 if the ray ends ~perpendicular to z (Helper.h:515).
  */
-int rt_oracle_march(const rt_ray *ray, int N, float dz0, const rt_gain *gain, int use_emis,
-                    int method, float c, float *gvl, float *evl, int32_t *ivl, rt_ray *ray_out,
-                    int *escaped_out, rt_oracle_counters *cnt)
+static int march_impl(const rt_ray *ray, int N, float dz0, const rt_gain *gain, int use_emis,
+                      int method, float c, float *gvl, float *evl, int32_t *ivl, rt_ray *ray_out,
+                      int *escaped_out, rt_oracle_counters *cnt, float *path /* [3*(3L+1)] or NULL */)
 {
     const int L = N - 1;
     for (int i = 0; i < L * RT_N_SUB; i++) {
@@ -259,6 +259,12 @@ int rt_oracle_march(const rt_ray *ray, int N, float dz0, const rt_gain *gain, in
         s.z = -s.z;
     }
     renormalise(&s);
+    if (path) { /* Helper.h:419-426: start point of the recorded path */
+        const int i0 = (method == 1) ? (N - 1) * RT_N_SUB : 0;
+        memset(path, 0, sizeof(float) * 3 * (size_t) (RT_N_SUB * (N - 1) + 1));
+        path[3 * i0 + 0] = pos.x;
+        path[3 * i0 + 1] = pos.y;
+    }
 
     int escaped    = 0;
     uint64_t steps = 0, it2 = 0, it1 = 0;
@@ -316,6 +322,11 @@ int rt_oracle_march(const rt_ray *ray, int N, float dz0, const rt_gain *gain, in
                 ivl[slot] = (int32_t) c00;
                 steps++;
             }
+            if (path) { /* Helper.h:505-511: position at the end of every sub-segment */
+                const int idx     = RT_N_SUB * (ii - 1) + is + (method == 1 ? 0 : 1);
+                path[3 * idx + 0] = pos.x;
+                path[3 * idx + 1] = pos.y;
+            }
         }
     }
     if (cnt) {
@@ -332,6 +343,13 @@ int rt_oracle_march(const rt_ray *ray, int N, float dz0, const rt_gain *gain, in
     ray_out->a = atanf(s.x / s.z) * 1e3f;
     ray_out->b = atanf(s.y / s.z) * 1e3f;
     return 0;
+}
+
+int rt_oracle_march(const rt_ray *ray, int N, float dz0, const rt_gain *gain, int use_emis,
+                    int method, float c, float *gvl, float *evl, int32_t *ivl, rt_ray *ray_out,
+                    int *escaped_out, rt_oracle_counters *cnt)
+{
+    return march_impl(ray, N, dz0, gain, use_emis, method, c, gvl, evl, ivl, ray_out, escaped_out, cnt, NULL);
 }
 
 /*
@@ -622,5 +640,83 @@ int rt_oracle_probe(int N, const rt_beam *beam, const rt_gain *gain, const rt_se
     free(g);
     free(e);
     free(c);
+    return RT_OK;
+}
+
+/*
+ * Path tracer: what RayTrace_calc_ray leaves in its `debug` array (Helper.h:419-426,
+ * 505-511, 536-542, 559-566) and RayTrace::calc_ray_path returns
+ * (src/RayTraceImage.cpp:440-477): for every ray the (x, y) position at the
+ * 3(N-1)+1 sub-segment boundaries and the frequency-integrated intensity
+ * sum_k 2 Iv_k dv_k after each sub-segment (float accumulation, k order).  With a
+ * debug array the reference always takes the per-sub-segment emission formula, also
+ * in seeded mode (Helper.h:543).  path: [n][3*(3L+1)] as {x, y, I} triples; err [n].
+ * c is the step safety factor (0.5 in create_image).
+ */
+int rt_oracle_calc_ray_path(int N, const rt_beam *beam, const rt_gain *gain, const rt_seed *seed,
+                            int method, float c, const rt_ray *rays, size_t n_rays, float *path,
+                            int32_t *err)
+{
+    const int K        = beam->nv;
+    const int L        = N - 1;
+    const int S        = L * RT_N_SUB;
+    const int N2       = S + 1;
+    const float dz0    = (float) beam->dz;
+    const int use_emis = gain[0].E0 != NULL && seed == NULL;
+    double *Iv   = (double *) malloc(sizeof(double) * (size_t) (K > 0 ? K : 1));
+    float *gvl   = (float *) malloc(sizeof(float) * (size_t) (S + 1));
+    float *evl   = (float *) malloc(sizeof(float) * (size_t) (S + 1));
+    int32_t *ivl = (int32_t *) malloc(sizeof(int32_t) * (size_t) (S + 1));
+    for (size_t r = 0; r < n_rays; r++) {
+        float *dbg = path + r * 3 * (size_t) N2;
+        rt_ray out = { 0, 0, 0, 0 };
+        int esc    = 0;
+        for (int k = 0; k < K; k++)
+            Iv[k] = 0.0;
+        int rc = march_impl(&rays[r], N, dz0, gain, use_emis, method, c, gvl, evl, ivl, &out, &esc, NULL, dbg);
+        err[r] = rc;
+        if (rc)
+            continue;
+        if (seed != NULL && !esc) {
+            if (method == 1)
+                seed_intensity(seed, out.x, out.y, (double) out.a, (double) out.b, Iv);
+            else if (method == 2)
+                seed_intensity(seed, rays[r].x, rays[r].y, rays[r].a, rays[r].b, Iv);
+        }
+        dbg[2] = 0.0f;
+        for (int k = 0; k < K; k++)
+            dbg[2] += (float) (2 * Iv[k] * beam->dv[k]);
+        for (int i = 0; i < L; i++) {
+            for (int is = 0; is < RT_N_SUB; is++) {
+                const int slot   = i * RT_N_SUB + is;
+                const float *row = &gain[i + 1].gv[(size_t) ivl[slot] * (size_t) K];
+                for (int k = 0; k < K; k++) {
+                    double gl = (double) (gvl[slot] * row[k]);
+                    double el = (double) (evl[slot] * row[k]);
+                    if (fabs(gl) < 1e-3) {
+                        Iv[k] = el * (1.0 + 0.5 * gl * (1.0 + 0.3333333333 * gl)) +
+                                Iv[k] * (1.0 + gl * (1.0 + 0.5 * gl));
+                    } else {
+                        double eg = exp(gl);
+                        Iv[k]     = el / gl * (eg - 1.0) + Iv[k] * eg;
+                    }
+                }
+                const int idx = 3 * (slot + 1) + 2;
+                dbg[idx]      = 0.0f;
+                for (int k = 0; k < K; k++)
+                    dbg[idx] += (float) (2 * Iv[k] * beam->dv[k]);
+            }
+        }
+        int neg = 0, nan = 0;
+        for (int k = 0; k < K; k++) {
+            neg = neg || Iv[k] < 0.0;
+            nan = nan || Iv[k] != Iv[k];
+        }
+        err[r] = neg ? -2 : (nan ? -3 : 0);
+    }
+    free(Iv);
+    free(gvl);
+    free(evl);
+    free(ivl);
     return RT_OK;
 }

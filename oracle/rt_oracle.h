@@ -43,6 +43,10 @@ int rt_oracle_probe(int N, const rt_beam *beam, const rt_gain *gain, const rt_se
                     int32_t *ivl, rt_ray *ray2, uint32_t *flags, uint32_t *steps, double *Iv,
                     int32_t *err);
 
+int rt_oracle_calc_ray_path(int N, const rt_beam *beam, const rt_gain *gain, const rt_seed *seed,
+                            int method, float c, const rt_ray *rays, size_t n_rays, float *path,
+                            int32_t *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,14 +69,16 @@ class HipLibrary:
 class Plan:
     """A problem resident in HBM: tables uploaded once, runnable many times."""
 
-    def __init__(self, problem: Problem, device: int = 0, lib: HipLibrary | None = None):
+    def __init__(self, problem: Problem, device: int = 0, lib: HipLibrary | None = None,
+                 method: int | None = None):
         self.hl = lib or HipLibrary.get()
         self.problem = problem
         self.device = device
         self._m = cabi.Marshalled(problem)
         self._h = C.c_void_p()
         rc = self.hl.lib.rt_hip_plan_create(C.byref(self._h), device, self._m.N, C.byref(self._m.beam),
-                                            self._m.gain, self._m.seed_ref, problem.method, problem.scale)
+                                            self._m.gain, self._m.seed_ref,
+                                            problem.method if method is None else method, problem.scale)
         self.hl.check(rc, "rt_hip_plan_create")
         self.n_rays = 0
 
@@ -89,15 +91,16 @@ class Plan:
         return self
 
     def set_ray_grid(self, first: int | None = None, stride: int | None = None,
-                     count: int | None = None) -> "Plan":
+                     count: int | None = None, grids=None) -> "Plan":
         """Rays generated on the device from the problem's ray grid
-        (RayTraceImage.cpp:300-328); defaults follow N_start / N_parallel."""
+        (RayTraceImage.cpp:300-328); defaults follow N_start / N_parallel.
+        `grids` = (x, y, a, b) overrides the problem's ray grid."""
         p = self.problem
-        gx, gy, ga, gb = p.ray_grid
+        gx, gy, ga, gb = p.ray_grid if grids is None else [np.ascontiguousarray(g, np.float64) for g in grids]
         first = p.N_start if first is None else first
         stride = p.N_parallel if stride is None else stride
         if count is None:
-            nt = p.n_rays_total
+            nt = len(gx) * len(gy) * len(ga) * len(gb)
             count = 0 if first >= nt else (nt - first + stride - 1) // stride
         self._grids = (gx, gy, ga, gb)
         self.hl.check(self.hl.lib.rt_hip_plan_set_ray_grid(
@@ -131,6 +134,24 @@ class Plan:
         self.hl.check(rc, "rt_hip_plan_fetch")
         return dict(image=image, I_ang=iang, failure_code=code.value, failed_rays=failed[:nf.value].copy(),
                     stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_})
+
+    def set_step_factor(self, c: float) -> "Plan":
+        self.hl.check(self.hl.lib.rt_hip_plan_set_step_factor(self._h, float(c)), "rt_hip_plan_set_step_factor")
+        return self
+
+    def enable_path(self, on: bool = True) -> "Plan":
+        self.hl.check(self.hl.lib.rt_hip_plan_enable_path(self._h, int(on)), "rt_hip_plan_enable_path")
+        return self
+
+    def fetch_path(self) -> dict:
+        """{x, y, I}: [n_rays][3(N-1)+1] float arrays, err: [n_rays] return codes."""
+        n = self.n_rays
+        N2 = (self.problem.N - 1) * cabi.RT_N_SUB + 1
+        path = np.zeros((n, N2, 3), np.float32)
+        err = np.zeros(n, np.int32)
+        self.hl.check(self.hl.lib.rt_hip_plan_fetch_path(self._h, cabi._fp(path), err.ctypes.data_as(C.POINTER(C.c_int32))),
+                      "rt_hip_plan_fetch_path")
+        return dict(x=path[:, :, 0].copy(), y=path[:, :, 1].copy(), I=path[:, :, 2].copy(), err=err)
 
     def kernel_ms(self) -> float:
         """Device time of the last run's trace kernel (waits for it)."""
@@ -241,3 +262,23 @@ def create_image(problem: Problem, method: str = "auto", device: int = 0, device
         msgs = [t for bit, t in _FAILURE_TEXT.items() if out["failure_code"] & (1 << bit)]
         raise RayTraceError("Some rays failed: " + "; ".join(msgs))
     return out
+
+
+def calc_ray_path(problem: Problem, x, y, a, b, method: int | None = None, c: float = 0.5, device: int = 0):
+    """Mirror of RayTrace::calc_ray_path (src/RayTraceImage.cpp:440-477): trace the rays of the
+    tensor grid x * y * a * b through the problem's tables and return the path of each ray.
+
+    Returns (xr, yr, Ir, n_errors): float32 arrays laid out as the reference lays them out,
+    index = N2 * (i + j*Nx + k*Nx*Ny + m*Nx*Ny*Na) + step with N2 = 3 (N-1) + 1, i.e. shape
+    [Nb][Na][Ny][Nx][N2] in C order."""
+    grids = [np.ascontiguousarray(g, np.float64) for g in (x, y, a, b)]
+    nx, ny, na, nb = (len(g) for g in grids)
+    with Plan(problem, device, method=method) as plan:
+        plan.set_step_factor(c).enable_path().set_ray_grid(0, 1, nx * ny * na * nb, grids=grids)
+        out = plan.run().fetch_path()
+    N2 = out["x"].shape[1]
+
+    def lay(v):  # ray order is i, j, k, m with m fastest
+        return np.ascontiguousarray(v.reshape(nx, ny, na, nb, N2).transpose(3, 2, 1, 0, 4))
+
+    return lay(out["x"]), lay(out["y"]), lay(out["I"]), int((out["err"] != 0).sum())

@@ -130,7 +130,13 @@ struct DevParams {
     // 1: every pixel receives exactly one ray of this launch (ASE, ray grid == beam grid,
     // na*nb == 1): the frequency kernel stores image rows instead of adding to them
     unsigned int exclusive;
-    unsigned int pad3;
+    // path tracer (RayTrace::calc_ray_path, src/RayTraceImage.cpp:440-477): when path != NULL
+    // the march records (x, y) at every sub-segment boundary and rt_path_kernel fills I
+    unsigned int path_on;
+    float *path;   // [n_rays][3 (N-1) + 1][3] = {x, y, I} triples, the reference's debug layout
+    int32_t *path_err; // [n_rays] return code of each ray
+    // step safety factor c of Helper.h:270-313 folded into its three uses (c = 0.5 in create_image)
+    float c_cap, c_h1, c_h3, pad4; // c*1.00001f, c*0.1f, c*0.05f
 };
 
 // flag bits of the per-ray march record

@@ -1,3 +1,4 @@
+#pragma once
 // rt_freq.hip -- kernel B: frequency integration + deposit (Helper.h:515-594,
 // RayTraceImageCPU.cpp:37-68) with lanes = rays.
 //
@@ -18,6 +19,10 @@
 #include "rt_march.hip"
 
 namespace rt {
+
+#ifndef RT_FREQ_WAVES
+#define RT_FREQ_WAVES 2 // minimum waves per SIMD the frequency kernel is compiled for
+#endif
 
 template <int VEC> struct FVec;
 template <> struct FVec<1> { float v[1]; };
@@ -405,7 +410,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 }
 
 template <int SF, int VEC>
-__global__ void __launch_bounds__(256) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
+__global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
 {
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];

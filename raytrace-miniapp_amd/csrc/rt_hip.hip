@@ -6,7 +6,8 @@
 // table into ONE arena, uploads it with ONE copy, zeroes outputs + control block
 // and launches the march kernel and the frequency kernel back to back on one
 // stream.  Nothing is cached across calls (Readme.txt:43).
-#include "rt_freq.hip"      // kernel B (includes rt_march.hip, kernel A)
+#include "rt_path.hip" // debug path tracer (before rt_freq.hip: no FMA contraction there)
+#include "rt_freq.hip" // kernel B (includes rt_march.hip, kernel A)
 
 #include <chrono>
 #include <cmath>
@@ -74,6 +75,10 @@ struct rt_hip_plan {
     float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
     std::vector<double> beam_x, beam_y, beam_a, beam_b; // host copies, to recognise ray grid == beam grid
     unsigned char *rec = nullptr; // per-ray march records (two-kernel path)
+    bool path_on       = false;   // path tracer instead of the image (rt_hip_plan_enable_path)
+    float *path_dev    = nullptr; // [n_rays][3L+1][3]
+    int32_t *path_err  = nullptr; // [n_rays]
+    size_t path_rays   = 0;
     size_t rec_bytes   = 0;
     hipEvent_t evm     = nullptr; // between march and frequency kernels
     double *image_own  = nullptr;
@@ -157,6 +162,23 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
     ch                    = ch < 64 ? 64 : (ch > 512 ? 512 : ch);
     p->P.chunk            = (unsigned) ((ch + 63) / 64 * 64);
+    p->P.path_on = p->path_on ? 1u : 0u;
+    if (p->path_on) {
+        const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
+        if (p->path_rays != (size_t) p->n_rays || !p->path_dev) {
+            (void) hipFree(p->path_dev);
+            (void) hipFree(p->path_err);
+            p->path_dev = nullptr;
+            p->path_err = nullptr;
+            HIP_TRY(hipMalloc((void **) &p->path_dev, (size_t) p->n_rays * n2 * 3 * sizeof(float) + 16));
+            HIP_TRY(hipMalloc((void **) &p->path_err, (size_t) p->n_rays * sizeof(int32_t) + 16));
+            p->path_rays = (size_t) p->n_rays;
+        }
+        HIP_TRY(hipMemsetAsync(p->path_dev, 0, (size_t) p->n_rays * n2 * 3 * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(p->path_err, 0, (size_t) p->n_rays * sizeof(int32_t), stream));
+        p->P.path     = p->path_dev;
+        p->P.path_err = p->path_err;
+    }
     HIP_TRY(hipEventRecord(p->ev0, stream));
     if (grid > 0) {
         if (lds_tab)
@@ -166,7 +188,13 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(p->evm, stream));
-    if (!(p->P.debug & 1u)) {
+    if (p->path_on) {
+        // the tracer replaces the frequency / deposit kernel: no image is produced
+        if (p->n_rays) {
+            hipLaunchKernelGGL(rt::rt_path_kernel, dim3((unsigned) ((p->n_rays + 255) / 256)), dim3(256), 0, stream, p->P);
+            HIP_TRY(hipGetLastError());
+        }
+    } else if (!(p->P.debug & 1u)) {
         const int S = p->P.L * RT_N_SUB, K = p->P.K;
         int rc;
         if (S == 6) {
@@ -208,6 +236,8 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         (void) hipEventDestroy(p->evm);
     (void) hipFree(p->tan_dev);
     (void) hipFree(p->rec);
+    (void) hipFree(p->path_dev);
+    (void) hipFree(p->path_err);
     (void) hipFree(p->arena);
     (void) hipFree(p->rays_dev);
     (void) hipFree(p->grid_dev);
@@ -415,6 +445,9 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipEventCreate(&p->evm));
     P.rec_stride = (unsigned) align_up((size_t) L * RT_N_SUB * 12 + sizeof(rt::RecMeta), 16);
+    P.c_cap      = 0.5f * 1.00001f; // step safety factor c = 0.5 (Helper.h:381), see rt_hip_plan_set_step_factor
+    P.c_h1       = 0.5f * 0.1f;
+    P.c_h3       = 0.5f * 0.05f;
     P.ctl = p->ctl;
     *out  = p;
     return RT_OK;
@@ -546,6 +579,39 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
                       own_cell(p->beam_b, p->P.beam.db))
                          ? 1u
                          : 0u;
+    return RT_OK;
+}
+
+int rt_hip_plan_set_step_factor(rt_hip_plan *p, double c)
+{
+    if (!p || !(c > 0.0) || !(c < 1.0))
+        return fail_arg("rt_hip_plan_set_step_factor: c must be in (0, 1)");
+    const float cf = (float) c; // RayTraceImage.cpp:462: (float) c at the call
+    p->P.c_cap     = cf * 1.00001f;
+    p->P.c_h1      = cf * 0.1f;
+    p->P.c_h3      = cf * 0.05f;
+    return RT_OK;
+}
+
+int rt_hip_plan_enable_path(rt_hip_plan *p, int on)
+{
+    if (!p)
+        return fail_arg("rt_hip_plan_enable_path: NULL plan");
+    p->path_on = on != 0;
+    return RT_OK;
+}
+
+int rt_hip_plan_fetch_path(rt_hip_plan *p, float *path, int32_t *err)
+{
+    if (!p || !p->ran || !p->path_on || !p->path_dev)
+        return fail_arg("rt_hip_plan_fetch_path: the path tracer was not enabled for the last run");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->last_stream));
+    const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
+    if (path)
+        HIP_TRY(hipMemcpy(path, p->path_dev, (size_t) p->n_rays * n2 * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (err)
+        HIP_TRY(hipMemcpy(err, p->path_err, (size_t) p->n_rays * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

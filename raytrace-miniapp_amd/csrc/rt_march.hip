@@ -1,3 +1,4 @@
+#pragma once
 // rt_march.hip -- kernel A: the float32 ray march (Helper.h:404-513) as a
 // persistent-lane state machine over LDS-resident plasma tables.
 //
@@ -210,6 +211,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     sz = -sz;
                 }
                 renormalise(sx, sy, sz);
+                if (P.path_on) { // Helper.h:419-426
+                    float *pp = P.path + (size_t) ridx * 3 * (size_t) (S + 1) + 3 * (size_t) (backward ? S : 0);
+                    pp[0]     = px;
+                    pp[1]     = py;
+                }
                 seg       = 0;
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
@@ -247,6 +253,15 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 reinterpret_cast<int *>(rec)[2 * S + slot] = cell_last;
 #endif
                 any_nz    = any_nz | (gacc != 0.0f) | (eacc != 0.0f);
+                if (P.path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
+                                 // segment records the same position, later segments stay zero
+                    float *pp = P.path + (size_t) ridx * 3 * (size_t) (S + 1);
+                    for (int zz = iz; zz < (escaped ? RT_N_SUB : iz + 1); zz++) {
+                        const int idx = RT_N_SUB * (ii - 1) + (backward ? RT_N_SUB - zz - 1 : zz + 1);
+                        pp[3 * idx]     = px;
+                        pp[3 * idx + 1] = py;
+                    }
+                }
                 gacc      = 0.0f;
                 eacc      = 0.0f;
                 cell_last = 0;
@@ -375,7 +390,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             if (mirror && py < 0)
                 gyn = -gyn;
             lim2  = dzrem - zc;
-            dzcap = 0.5f * 1.00001f * lim2; // Helper.h:274 with c = 0.5
+            dzcap = P.c_cap * lim2; // Helper.h:274: c * 1.00001f * dx[2]
             rx    = 0.0f;
             ry    = 0.0f;
             rz    = 0.0f;
@@ -387,7 +402,6 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 
         // ------------------------------------------------------------ [C] one integrator step (Helper.h:279-311)
         if (st == ST_STEP) {
-            const float c    = 0.5f;
             const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
             // (double)|n - n0| < 0.05 (Helper.h:280) <=> |n - n0| < 0.05f: 0.05f is the smallest float above 0.05
             bool run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & (fabsf(n - n0) < 0.05f);
@@ -398,11 +412,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 float fx = div_by_recip(gxn, n, rn) - sx * t;
                 float fy = div_by_recip(gyn, n, rn) - sy * t;
                 float fz = -sz * t;
-                float h  = c * 0.1f / fabsf(t);
+                float h  = P.c_h1 / fabsf(t); // c * 0.1f / |t|
                 h        = h < dzcap ? h : dzcap;
                 float h2 = 1.0001f * (lim2 - fabsf(rz)) / fabsf(sz);
-                float h3 = c * 0.05f * (fabsf(sx) + 5e-4f) / (fabsf(fx) + 1e-8f);
-                float h4 = c * 0.05f * (fabsf(sy) + 5e-4f) / (fabsf(fy) + 1e-8f);
+                float h3 = P.c_h3 * (fabsf(sx) + 5e-4f) / (fabsf(fx) + 1e-8f); // c * 0.05f * ...
+                float h4 = P.c_h3 * (fabsf(sy) + 5e-4f) / (fabsf(fy) + 1e-8f);
                 h        = h < h2 ? h : h2;
                 h        = h < h3 ? h : h3;
                 h        = h < h4 ? h : h4;

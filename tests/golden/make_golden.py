@@ -14,6 +14,8 @@ Writes, for each shipped input (ASE_small, seed_small):
                          RayTraceImageCPULoop), compiled by oracle/Makefile
   <name>_ref_rays.npz    RayTrace::calc_ray outputs (Iv, exit ray, error) of
                          every STRIDE-th ray of the reference's own ray list
+  <name>_ref_path.npz    RayTrace::calc_ray_path outputs (x, y, I per sub-segment
+                         boundary) on a small sub-grid, step factors 0.5 and 0.25
 Only data is stored -- no reference source text in any encoding.
 """
 import hashlib
@@ -53,6 +55,14 @@ def main():
         q = ref.calc_rays_file(src, STRIDE[name], n)
         np.savez_compressed(OUT / f"{name}_ref_rays.npz", stride=STRIDE[name], Iv=q["Iv"],
                             ray2=q["ray2"], rays=q["rays"], err=q["err"])
+        # RayTrace::calc_ray_path (the debug tracer) on a small sub-grid, two step factors
+        sub = {"ASE_small": ((20, 3, 2, 1), (5, 4, 6, 5)), "seed_small": ((40, 2, 10, 12), (4, 3, 5, 6))}[name]
+        paths = {}
+        for c in (0.5, 0.25):
+            t = ref.calc_ray_path_file(src, sub[0], sub[1], c)
+            paths[f"x_c{c}"], paths[f"y_c{c}"], paths[f"I_c{c}"] = t["x"], t["y"], t["I"]
+            paths[f"nerr_c{c}"] = t["n_errors"]
+        np.savez_compressed(OUT / f"{name}_ref_path.npz", i0=np.array(sub[0]), n=np.array(sub[1]), **paths)
         print(f"{name}: |image|={np.linalg.norm(r['image']):.12g} |I_ang|={np.linalg.norm(r['I_ang']):.12g} "
               f"ref cpu {r['seconds']:.2f}s, {n} probe rays")
 

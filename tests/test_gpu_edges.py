@@ -192,3 +192,36 @@ def test_seeded_subsets_and_list_path(hip, oracle, seed_small):
     assert np.array_equal(out["probe"]["ray2"]["x"][ok], ora["ray2"]["x"][ok])
     assert np.allclose(out["probe"]["ray2"]["a"][ok], ora["ray2"]["a"][ok], rtol=3e-7, atol=0)
     assert rel_l2(out["image"], ref["image"]) < TOL and rel_l2(out["I_ang"], ref["I_ang"]) < TOL
+
+
+def test_path_tracer_matches_calc_ray_path(hip, oracle):
+    """(f-4) RayTrace::calc_ray_path on the GPU: positions bit-exact, intensities to float
+    rounding, against the reference's own outputs (fixture) and the oracle, two step factors."""
+    import importlib
+    from conftest import GOLDEN
+    for name in ("ASE_small", "seed_small"):
+        p = rt.datfile.load(GOLDEN / f"{name}.dat.xz")
+        fx = np.load(GOLDEN / f"{name}_ref_path.npz")
+        i0, n = fx["i0"], fx["n"]
+        gx, gy, ga, gb = p.ray_grid
+        sub = [g[s:s + c] for g, s, c in zip((gx, gy, ga, gb), i0, n)]
+        for c in (0.5, 0.25):
+            xr, yr, Ir, nerr = hip.calc_ray_path(p, *sub, c=c)
+            assert nerr == int(fx[f"nerr_c{c}"])
+            assert np.array_equal(xr.view(np.uint32), fx[f"x_c{c}"].view(np.uint32))
+            assert np.array_equal(yr.view(np.uint32), fx[f"y_c{c}"].view(np.uint32))
+            assert np.allclose(Ir, fx[f"I_c{c}"], rtol=2e-6, atol=0)
+            assert float(np.abs(fx[f"I_c{c}"]).max()) > 0
+
+
+def test_path_tracer_escaped_and_failed_rays(hip, oracle, ase_small):
+    rays = ase_small.build_rays(np.arange(0, ase_small.n_rays_total, 331, dtype=np.int64))
+    rays["a"][5] = 1500.0      # error -1
+    rays["x"][9] = 10.0        # outside the plasma from the start
+    with hip.Plan(ase_small) as plan:
+        got = plan.enable_path().set_rays(rays).run().fetch_path()
+    want = oracle.calc_ray_path(ase_small, rays)
+    assert np.array_equal(got["err"], want["err"]) and got["err"][5] == -1
+    assert np.array_equal(got["x"].view(np.uint32), want["x"].view(np.uint32))
+    assert np.array_equal(got["y"].view(np.uint32), want["y"].view(np.uint32))
+    assert np.allclose(got["I"], want["I"], rtol=2e-6, atol=0)

@@ -113,3 +113,23 @@ def test_frequency_slicing_property(oracle, ase_small):
         ang += part["I_ang"]
     assert np.array_equal(img.reshape(-1), full["image"])
     assert rel_l2(ang, full["I_ang"]) < 1e-14
+
+
+@pytest.mark.parametrize("name", ["ASE_small", "seed_small"])
+def test_path_tracer_bitwise_vs_reference_calc_ray_path(oracle, name):
+    """Oracle restatement of the `debug` path (Helper.h:419-426, 505-511, 536-566) against
+    RayTrace::calc_ray_path outputs of the compiled reference (fixture), two step factors."""
+    p = rt.datfile.load(GOLDEN / f"{name}.dat.xz")
+    fx = np.load(GOLDEN / f"{name}_ref_path.npz")
+    i0, n = fx["i0"], fx["n"]
+    gx, gy, ga, gb = p.ray_grid
+    I, J, K_, M = np.meshgrid(*[np.arange(c) + s for s, c in zip(i0, n)], indexing="ij")
+    ids = ((I * len(gy) + J) * len(ga) + K_) * len(gb) + M
+    rays = p.build_rays(ids.reshape(-1).astype(np.int64))
+    for c in (0.5, 0.25):
+        out = oracle.calc_ray_path(p, rays, c)
+        N2 = out["x"].shape[1]
+        for key in "xyI":
+            mine = out[key].reshape(*n, N2).transpose(3, 2, 1, 0, 4)
+            assert np.array_equal(mine.view(np.uint32), fx[f"{key}_c{c}"].view(np.uint32))
+        assert int((out["err"] != 0).sum()) == int(fx[f"nerr_c{c}"])
