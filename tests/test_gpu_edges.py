@@ -225,3 +225,38 @@ def test_path_tracer_escaped_and_failed_rays(hip, oracle, ase_small):
     assert np.array_equal(got["x"].view(np.uint32), want["x"].view(np.uint32))
     assert np.array_equal(got["y"].view(np.uint32), want["y"].view(np.uint32))
     assert np.allclose(got["I"], want["I"], rtol=2e-6, atol=0)
+
+
+def test_non_uniform_gain_grid_takes_the_bisection_fallback(hip, oracle, ase_small):
+    """The arithmetic index guess is only exact on uniform grids; a stretched grid must
+    give the same cells through the bisection fallback (Helper.h:131-143)."""
+    p = copy.copy(ase_small)
+    gains = [ase_small.gain[0]]
+    for g in ase_small.gain[1:]:
+        t = np.linspace(0.0, 1.0, g.Nx)
+        x2 = g.x[0] + (g.x[-1] - g.x[0]) * (0.35 * t + 0.65 * t ** 3)       # strongly non-uniform, monotone
+        s = np.linspace(0.0, 1.0, g.Ny)
+        y2 = g.y[0] + (g.y[-1] - g.y[0]) * (0.5 * s + 0.5 * s ** 2)
+        gains.append(rt.Gain(x2, y2, g.n, g.g0, g.E0, g.gv, g.Nv))
+    p.gain = gains
+    rays = p.build_rays(np.arange(0, p.n_rays_total, 173, dtype=np.int64))
+    out = run_hip(hip, p, rays, probe=True)
+    same_record(out["probe"], oracle.probe(p, rays, want_Iv=False))
+    ref = oracle.image_loop(p, rays)
+    assert rel_l2(out["image"], ref["image"]) < TIGHT and rel_l2(out["I_ang"], ref["I_ang"]) < TIGHT
+
+
+@pytest.mark.parametrize("nv", [1, 3, 6, 50])
+def test_small_and_odd_frequency_counts(hip, oracle, ase_small, nv):
+    """VEC = 1 (odd K), 2 (K = 2 mod 4) and 4 code paths of the frequency kernel."""
+    p = problem_mod.resample_frequency(ase_small, nv) if nv > 1 else None
+    if p is None:
+        p = copy.copy(ase_small)
+        p.beam = copy.copy(ase_small.beam)
+        p.beam.dv = np.ascontiguousarray(ase_small.beam.dv[20:21])
+        p.gain = [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, g.gv.reshape(-1, 52)[:, 20:21].copy(), 1) for g in ase_small.gain]
+    rays = p.build_rays(np.arange(0, p.n_rays_total, 257, dtype=np.int64))
+    out = run_hip(hip, p, rays)
+    ref = oracle.image_loop(p, rays)
+    assert out["failure_code"] == 0
+    assert rel_l2(out["image"], ref["image"]) < TIGHT and rel_l2(out["I_ang"], ref["I_ang"]) < TIGHT
