@@ -188,7 +188,7 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "ms_per_image": ms_step, "kernel_ms": kernel_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 march + f64 frequency integration",
+            "dtype": "f32+f64",  # float32 march (bit-exact), float64 frequency integration
             "data": "ASE_small.dat plasma tables (reference input) on the synthetic scale_problem(16) ray grid; "
                     "ASE_medium.dat itself is absent from the reference checkout",
             "config": {"workload": full.label, "rays_per_gpu": stats["n_rays"], "rays_total": rays_all,

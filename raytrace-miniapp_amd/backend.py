@@ -54,6 +54,13 @@ class HipLibrary:
     @classmethod
     def get(cls) -> "HipLibrary":
         if cls._instance is None:
+            if not LIB_PATH.exists():
+                # a fresh checkout (built files are not in history): compile in-tree with hipcc;
+                # if that is impossible the constructor below raises -- there is no other path
+                try:
+                    build_library()
+                except Exception as exc:  # noqa: BLE001
+                    raise RayTraceError(f"HIP backend library {LIB_PATH} is missing and could not be built: {exc}") from exc
             cls._instance = HipLibrary()
         return cls._instance
 

@@ -160,8 +160,8 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     // rays reserved per counter fetch: big enough to amortise the atomic, small enough
     // that the last chunks balance (about 8 chunks per wave)
     unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
-    ch                    = ch < 64 ? 64 : (ch > 512 ? 512 : ch);
-    p->P.chunk            = (unsigned) ((ch + 63) / 64 * 64);
+    ch                    = ch < 16 ? 16 : (ch > 512 ? 512 : ch);
+    p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
     p->P.path_on = p->path_on ? 1u : 0u;
     if (p->path_on) {
         const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
