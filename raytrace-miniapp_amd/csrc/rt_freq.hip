@@ -154,8 +154,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         rt_ray r2 = { m.px, m.py, 0.0f, 0.0f };
         if (need_exit) {
             // Helper.h:518-521: atanf(s.x / s.z) * 1e3f
-            r2.a = (float) atan((double) (m.sx / m.sz)) * 1e3f;
-            r2.b = (float) atan((double) (m.sy / m.sz)) * 1e3f;
+            r2.a = atanf_flt32_kernel(m.sx / m.sz) * 1e3f;
+            r2.b = atanf_flt32_kernel(m.sy / m.sz) * 1e3f;
         }
         if (P.has_seed && !(fl & F_ESCAPED)) { // Helper.h:523-533
             if (P.method == 1)

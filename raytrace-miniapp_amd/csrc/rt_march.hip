@@ -64,15 +64,63 @@ __device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray
     }
 }
 
-// list mode: tangents of the launch angles (Helper.h:409-410), f64 tan rounded to
-// float == tanf on the angle range (tests/test_float_identities.py)
+// tanf as the reference's libm computes it.  Helper.h:409-410 calls tanf(1e-3f * a); on
+// the reference platform that is GNU libc 2.35, sysdeps/ieee754/flt-32/{s,k}_tanf.c --
+// the fdlibm float kernel: for |x| < 0.6744 a degree-13 odd polynomial evaluated in float
+// in a fixed order.  Restated here (same coefficients, same order, no FMA contraction);
+// tests/test_float_identities.py checks the restatement against the host tanf for every
+// float in [4.6e-10, 0.2].  Launch angles beyond 200 mrad fall back to the float-rounded
+// f64 tan (the float kernel's large-argument branches are not restated).
+__device__ __forceinline__ float tanf_flt32_kernel(float x)
+{
+    const float ax = fabsf(x);
+    if (ax < 0x1p-13f) // s_tanf.c/k_tanf.c: (int) x == 0 -> return x
+        return x;
+    if (ax > 0.2f)
+        return (float) tan((double) x);
+    const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
+                T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
+                T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,
+                T12 = 2.5907305826e-05f;
+    const float z = x * x;
+    const float w = z * z;
+    float r       = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    const float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    const float s = z * x;
+    r             = 0.0f + z * (s * (r + v) + 0.0f);
+    r += T0 * s;
+    return x + r;
+}
+
+// atanf, likewise (Helper.h:520-521: atan(s.x / s.z) * 1e3f): glibc 2.35 flt-32 s_atanf.c,
+// the |x| < 7/16 branch (exit directions are far inside it); checked against the host atanf
+// for every float of that range by tests/test_float_identities.py.
+__device__ __forceinline__ float atanf_flt32_kernel(float x)
+{
+    const float ax = fabsf(x);
+    if (ax < 0x1p-29f)
+        return x;
+    if (!(ax < 0.4375f))
+        return (float) atan((double) x);
+    const float A0 = 3.3333334327e-01f, A1 = -2.0000000298e-01f, A2 = 1.4285714924e-01f, A3 = -1.1111110449e-01f,
+                A4 = 9.0908870101e-02f, A5 = -7.6918758452e-02f, A6 = 6.6610731184e-02f, A7 = -5.8335702866e-02f,
+                A8 = 4.9768779427e-02f, A9 = -3.6531571299e-02f, A10 = 1.6285819933e-02f;
+    const float z  = x * x;
+    const float w  = z * z;
+    const float s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
+    const float s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
+    return x - x * (s1 + s2);
+}
+
+// list mode: tangents of the launch angles (Helper.h:409-410) for every ray, at full lane
+// occupancy, before the march
 extern "C" __global__ void __launch_bounds__(256) rt_tan_kernel(const rt_ray *rays, unsigned long long n, float *sxy)
 {
     unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         rt_ray r       = rays[i];
-        sxy[2 * i]     = (float) tan((double) (1e-3f * r.a));
-        sxy[2 * i + 1] = (float) tan((double) (1e-3f * r.b));
+        sxy[2 * i]     = tanf_flt32_kernel(1e-3f * r.a);
+        sxy[2 * i + 1] = tanf_flt32_kernel(1e-3f * r.b);
     }
 }
 

@@ -32,8 +32,8 @@ extern "C" __global__ void __launch_bounds__(256) rt_path_kernel(const DevParams
     double f0 = 0.0;
     if (P.has_seed && !(fl & F_ESCAPED)) { // Helper.h:523-533
         if (P.method == 1) {
-            const float a2 = (float) atan((double) (m.sx / m.sz)) * 1e3f;
-            const float b2 = (float) atan((double) (m.sy / m.sz)) * 1e3f;
+            const float a2 = atanf_flt32_kernel(m.sx / m.sz) * 1e3f;
+            const float b2 = atanf_flt32_kernel(m.sy / m.sz) * 1e3f;
             f0             = seed_factor(P.seed, (double) m.px, (double) m.py, (double) a2, (double) b2);
         } else {
             f0 = seed_factor(P.seed, (double) ray.x, (double) ray.y, (double) ray.a, (double) ray.b);

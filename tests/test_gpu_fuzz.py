@@ -1,0 +1,112 @@
+"""Randomised parity: random mixtures of lengths, frequency counts, stretched / shifted
+gain grids, launch positions and angles (including rays that start outside the plasma,
+graze its edge, or run nearly parallel to a cell boundary), ASE and seeded tables, list
+and grid ray modes.  Every case: march record bit-exact, image / I_ang under the tight
+float64 gate, failure codes equal."""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+rt = importlib.import_module("raytrace-miniapp_amd")
+problem_mod = importlib.import_module("raytrace-miniapp_amd.problem")
+pytestmark = pytest.mark.gpu
+
+
+def random_case(rng, ase_small, seed_small):
+    seeded = rng.random() < 0.4
+    base = seed_small if seeded else ase_small
+    p = copy.copy(base)
+    K0 = base.beam.nv
+    # lengths: N in 2..6, tables picked from the two shipped ones, optionally perturbed
+    N = int(rng.integers(2, 7))
+    gains = [base.gain[0]]
+    for i in range(N - 1):
+        g = base.gain[1 + int(rng.integers(0, 2))]
+        x, y, n = g.x, g.y, g.n
+        if rng.random() < 0.3:  # non-uniform grid
+            t = np.linspace(0, 1, g.Nx)
+            x = g.x[0] + (g.x[-1] - g.x[0]) * (0.6 * t + 0.4 * t ** 2)
+        if rng.random() < 0.3:  # stronger index gradients -> more integrator steps
+            n = 1.0 - (1.0 - g.n) * float(rng.uniform(0.2, 3.0))
+        gains.append(rt.Gain(x, y, n, g.g0 * np.float32(rng.uniform(0.3, 1.5)), g.E0, g.gv, g.Nv))
+    p.gain = gains
+    if rng.random() < 0.5:  # other frequency counts (VEC 1 / 2 / 4, chunks of 64)
+        p = problem_mod.resample_frequency(p, int(rng.choice([5, 18, 52, 66, 100])))
+    if rng.random() < 0.3:  # other dz
+        p.beam = copy.copy(p.beam)
+        p.beam.dz = float(p.beam.dz * rng.uniform(0.5, 2.0))
+    n = int(rng.integers(1, 1500))
+    rays = np.zeros(n, dtype=rt.cabi.RAY_DTYPE)
+    gx, gy, ga, gb = p.ray_grid
+    gxx, gyy = base.gain[1].x, base.gain[1].y
+    rays["x"] = rng.uniform(gxx[0] - 0.1 * (gxx[-1] - gxx[0]), gxx[-1] + 0.1 * (gxx[-1] - gxx[0]), n)
+    rays["y"] = rng.uniform(-1.1 * gyy[-1], 1.1 * gyy[-1], n) if rng.random() < 0.5 else rng.uniform(0, gyy[-1], n)
+    # list mode evaluates tanf on the device with the restated libm float kernel (valid to
+    # 200 mrad); grid mode (below) takes the tangents from the host libm
+    spread = float(rng.choice([5.0, 20.0, 60.0, 150.0]))
+    rays["a"] = rng.uniform(-spread, spread, n)
+    rays["b"] = rng.uniform(-spread, spread, n)
+    k = max(1, n // 10)   # some rays exactly on grid lines / corners
+    rays["x"][:k] = rng.choice(gxx, k).astype(np.float32)
+    rays["y"][k:2 * k] = rng.choice(gyy, min(k, n - k)).astype(np.float32)[: max(0, min(k, n - k))]
+    return p, rays
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_problem_matches_oracle(hip, oracle, ase_small, seed_small, seed):
+    rng = np.random.default_rng(1000 + seed)
+    p, rays = random_case(rng, ase_small, seed_small)
+    with hip.Plan(p) as plan:
+        plan.set_rays(rays).enable_probe().run()
+        out = plan.fetch()
+        pr = plan.fetch_probe()
+    ora = oracle.probe(p, rays, want_Iv=False)
+    ref = oracle.image_loop(p, rays)
+    assert np.array_equal(pr["steps"], ora["steps"])
+    assert np.array_equal(pr["flags"] & 3, ora["flags"] & 3)
+    assert np.array_equal(pr["ivl"], ora["ivl"])
+    assert np.array_equal(pr["gvl"].view(np.uint32), ora["gvl"].view(np.uint32))
+    assert np.array_equal(pr["evl"].view(np.uint32), ora["evl"].view(np.uint32))
+    assert out["failure_code"] == ref["failure_code"]
+    assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    if ref["failure_code"] == 0:
+        for key in ("image", "I_ang"):
+            if np.linalg.norm(ref[key]) > 0:
+                assert rel_l2(out[key], ref[key]) < 1e-10
+            else:
+                assert not out[key].any()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_wide_angle_grids_match_oracle(hip, oracle, ase_small, seed_small, seed):
+    """Grid mode with launch angles up to +-80 mrad (tangents from the host libm: exact)."""
+    rng = np.random.default_rng(5000 + seed)
+    p, _ = random_case(rng, ase_small, seed_small)
+    gxx, gyy = p.gain[1].x, p.gain[1].y
+    grids = [np.sort(rng.uniform(gxx[0], gxx[-1], 5)), np.sort(rng.uniform(0.0, gyy[-1], 4)),
+             np.sort(rng.uniform(-80, 80, 7)), np.sort(rng.uniform(-80, 80, 6))]
+    q = copy.copy(p)
+    if p.seed is None:   # ASE: the ray grid is the beam grid
+        q.beam = copy.copy(p.beam)
+        q.beam.x, q.beam.y, q.beam.a, q.beam.b = grids
+    else:
+        q.seed_beam = copy.copy(p.seed_beam)
+        q.seed_beam.x, q.seed_beam.y, q.seed_beam.a, q.seed_beam.b = grids
+    rays = q.build_rays()
+    with hip.Plan(q) as plan:
+        plan.set_ray_grid().enable_probe().run()
+        out = plan.fetch()
+        pr = plan.fetch_probe()
+    ora = oracle.probe(q, rays, want_Iv=False)
+    ref = oracle.image_loop(q, rays)
+    assert np.array_equal(pr["steps"], ora["steps"])
+    assert np.array_equal(pr["ivl"], ora["ivl"])
+    assert np.array_equal(pr["gvl"].view(np.uint32), ora["gvl"].view(np.uint32))
+    assert np.array_equal(pr["evl"].view(np.uint32), ora["evl"].view(np.uint32))
+    assert out["failure_code"] == ref["failure_code"]
+    if ref["failure_code"] == 0 and np.linalg.norm(ref["image"]) > 0:
+        assert rel_l2(out["image"], ref["image"]) < 1e-10

@@ -1,0 +1,23 @@
+import importlib, sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+rt = importlib.import_module("raytrace-miniapp_amd")
+be = importlib.import_module("raytrace-miniapp_amd.backend")
+from oracle.binding import Oracle
+from test_gpu_fuzz import random_case
+seed = int(sys.argv[1])
+a = rt.datfile.load('tests/golden/ASE_small.dat.xz'); s = rt.datfile.load('tests/golden/seed_small.dat.xz')
+rng = np.random.default_rng(1000 + seed)
+p, rays = random_case(rng, a, s)
+print("N", p.N, "K", p.beam.nv, "seeded", p.seed is not None, "rays", len(rays), "dz", p.beam.dz)
+with be.Plan(p) as plan:
+    plan.set_rays(rays).enable_probe().run(); out = plan.fetch(); pr = plan.fetch_probe()
+ora = Oracle().probe(p, rays, want_Iv=False)
+bad = np.where((pr["gvl"].view(np.uint32) != ora["gvl"].view(np.uint32)).any(axis=1) | (pr["evl"].view(np.uint32) != ora["evl"].view(np.uint32)).any(axis=1))[0]
+print("bad rays", len(bad), bad[:10])
+for r in bad[:5]:
+    print("ray", r, rays[r], "steps", pr["steps"][r], ora["steps"][r], "flags", pr["flags"][r], ora["flags"][r])
+    print("  gvl hip", pr["gvl"][r]); print("  gvl ora", ora["gvl"][r])
+    print("  ulp diff", pr["gvl"][r].view(np.int32) - ora["gvl"][r].view(np.int32))
+    print("  evl diff", pr["evl"][r].view(np.int32) - ora["evl"][r].view(np.int32), "ivl eq", np.array_equal(pr["ivl"][r], ora["ivl"][r]))
+    print("  ray2 hip", pr["ray2"][r], "ora", ora["ray2"][r])
