@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -61,6 +63,83 @@ struct ArenaBuilder {
         return off;
     }
 };
+
+// Device-memory pool: create_image is called once per iteration of the application and may
+// not keep DATA across calls (Readme.txt:43), but nothing forbids keeping ALLOCATIONS: the
+// ray list (16 B/ray), the tangents and the march records (96 B/ray) are hundreds of MB per
+// call and hipMalloc/hipFree of them costs milliseconds.  Freed blocks are parked per device
+// (at most POOL_MAX_BLOCKS, POOL_MAX_BYTES) and handed out again best-fit.
+constexpr size_t POOL_MAX_BLOCKS = 8;
+constexpr size_t POOL_MAX_BYTES  = (size_t) 32 << 30;
+constexpr size_t POOL_MIN_BYTES  = (size_t) 1 << 20; // small blocks are not worth parking
+struct PoolBlock {
+    int device;
+    void *ptr;
+    size_t bytes;
+};
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+std::unordered_map<void *, size_t> g_pool_sizes; // live blocks handed out by pool_alloc
+
+hipError_t pool_alloc(int device, void **out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes == 0)
+        bytes = 16;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        int best = -1;
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].device == device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + POOL_MIN_BYTES &&
+                (best < 0 || g_pool[i].bytes < g_pool[(size_t) best].bytes))
+                best = (int) i;
+        if (best >= 0) {
+            *out                 = g_pool[(size_t) best].ptr;
+            g_pool_sizes[*out]   = g_pool[(size_t) best].bytes;
+            g_pool.erase(g_pool.begin() + best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) { // out of memory: drop the parked blocks and retry once
+        std::vector<PoolBlock> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mutex);
+            drop.swap(g_pool);
+        }
+        for (auto &b : drop)
+            (void) hipFree(b.ptr);
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        g_pool_sizes[*out] = bytes;
+    }
+    return e;
+}
+
+void pool_free(int device, void *ptr)
+{
+    if (!ptr)
+        return;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto it = g_pool_sizes.find(ptr);
+        if (it != g_pool_sizes.end()) {
+            bytes = it->second;
+            g_pool_sizes.erase(it);
+        }
+        size_t held = 0;
+        for (auto &b : g_pool)
+            held += b.bytes;
+        if (bytes >= POOL_MIN_BYTES && g_pool.size() < POOL_MAX_BLOCKS && held + bytes <= POOL_MAX_BYTES) {
+            g_pool.push_back({ device, ptr, bytes });
+            return;
+        }
+    }
+    (void) hipFree(ptr);
+}
 
 } // namespace
 
@@ -131,9 +210,9 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
 {
     const size_t need = (size_t) p->n_rays * p->P.rec_stride;
     if (need > p->rec_bytes || !p->rec) {
-        (void) hipFree(p->rec);
+        pool_free(p->device, p->rec);
         p->rec = nullptr;
-        HIP_TRY(hipMalloc((void **) &p->rec, need ? need : 16));
+        HIP_TRY(pool_alloc(p->device, (void **) &p->rec, need ? need : 16));
         p->rec_bytes = need;
     }
     p->P.rec = p->rec;
@@ -234,12 +313,12 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         (void) hipEventDestroy(p->ev1);
     if (p->evm)
         (void) hipEventDestroy(p->evm);
-    (void) hipFree(p->tan_dev);
-    (void) hipFree(p->rec);
+    pool_free(p->device, p->tan_dev);
+    pool_free(p->device, p->rec);
     (void) hipFree(p->path_dev);
     (void) hipFree(p->path_err);
     (void) hipFree(p->arena);
-    (void) hipFree(p->rays_dev);
+    pool_free(p->device, p->rays_dev);
     (void) hipFree(p->grid_dev);
     (void) hipFree(p->image_own);
     (void) hipFree(p->iang_own);
@@ -458,17 +537,17 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
     if (!p || (n_rays && !rays))
         return fail_arg("rt_hip_plan_set_rays: NULL argument");
     HIP_TRY(hipSetDevice(p->device));
-    (void) hipFree(p->rays_dev);
+    pool_free(p->device, p->rays_dev);
     p->rays_dev = nullptr;
     if (n_rays) {
-        HIP_TRY(hipMalloc((void **) &p->rays_dev, n_rays * sizeof(rt_ray)));
+        HIP_TRY(pool_alloc(p->device, (void **) &p->rays_dev, n_rays * sizeof(rt_ray)));
         HIP_TRY(hipMemcpy(p->rays_dev, rays, n_rays * sizeof(rt_ray), hipMemcpyHostToDevice));
     }
-    (void) hipFree(p->tan_dev);
+    pool_free(p->device, p->tan_dev);
     p->tan_dev = nullptr;
     if (n_rays) {
         // Helper.h:409-410 for every ray, at full lane occupancy, before the march
-        HIP_TRY(hipMalloc((void **) &p->tan_dev, n_rays * 2 * sizeof(float)));
+        HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, n_rays * 2 * sizeof(float)));
         const unsigned blocks = (unsigned) ((n_rays + 255) / 256);
         hipLaunchKernelGGL(rt::rt_tan_kernel, dim3(blocks), dim3(256), 0, nullptr, p->rays_dev,
                            (unsigned long long) n_rays, p->tan_dev);
@@ -513,9 +592,9 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
         ht[(size_t) k] = tanf(1e-3f * (float) ga[k]);
     for (int m = 0; m < ngb; m++)
         ht[(size_t) nga + (size_t) m] = tanf(1e-3f * (float) gb[m]);
-    (void) hipFree(p->tan_dev);
+    pool_free(p->device, p->tan_dev);
     p->tan_dev = nullptr;
-    HIP_TRY(hipMalloc((void **) &p->tan_dev, ht.size() * sizeof(float)));
+    HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, ht.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(p->tan_dev, ht.data(), ht.size() * sizeof(float), hipMemcpyHostToDevice));
     rt::DevRays &R = p->P.rays;
     R              = {};
