@@ -21,7 +21,7 @@
 namespace rt {
 
 #ifndef RT_FREQ_WAVES
-#define RT_FREQ_WAVES 2 // minimum waves per SIMD the frequency kernel is compiled for
+#define RT_FREQ_WAVES 4 // waves per SIMD the frequency kernel is compiled for (<= 128 VGPRs)
 #endif
 
 template <int VEC> struct FVec;
@@ -209,47 +209,20 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     }
 
     // ---- runs of equal pixel index (built once per tile) --------------------------
-    const int pix_prev = __shfl_up(pix, 1, WAVE);
-    const bool head    = lane == 0 || pix_prev != pix;
-    int run_start      = head ? lane : -1;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int t = __shfl_up(run_start, o, WAVE);
-        if (lane >= o && t > run_start)
-            run_start = t;
-    }
-    const int head_next = __shfl_down(head ? 1 : 0, 1, WAVE);
-    const bool tail     = (lane == WAVE - 1 || head_next != 0) && pix >= 0;
-    bool addm[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-        addm[i] = (lane - (1 << i)) >= run_start;
-    // Few runs (ASE: a tile lies inside one pixel, or straddles two): one DPP wave sum
-    // per run and frequency, totals parked in lane (k mod 64) and flushed as ONE
-    // coalesced atomic per run and 64 frequencies.  Many runs (seeded): the segmented
-    // scan below.
+    // Few runs (ASE: a tile lies inside one pixel, or straddles two): one DPP wave sum per
+    // run and frequency, totals parked in lane (k mod 64) and flushed as ONE coalesced atomic
+    // per run and 64 frequencies.  More runs (seeded mode: ~7 per tile): every run owns one
+    // row of the wave's LDS row cache [nslot][K]; lanes add into their run's row with LDS f64
+    // atomics, rows are flushed per tile with coalesced atomics.  Beyond the cache: a
+    // segmented shuffle scan.
     constexpr int MAXQ               = 3;
-    const unsigned long long head_m  = __ballot(head);
+    const int pix_before             = __shfl_up(pix, 1, WAVE);
+    const unsigned long long head_m  = __ballot(lane == 0 || pix_before != pix);
     const int n_runs                 = (int) __popcll(head_m);
     const bool few                   = n_runs <= MAXQ;
-    // more runs than that (seeded mode: ~7 per tile): every run owns one row of the
-    // wave's LDS row cache [nslot][K]; lanes add into their run's row with LDS f64
-    // atomics, rows are flushed per tile with coalesced atomics.
     const bool cached                = !few && n_runs <= nslot;
     const unsigned long long le_mask = (lane == WAVE - 1) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
     const int run_id                 = (int) __popcll(head_m & le_mask) - 1;
-    int pixq[MAXQ];
-    double outq[MAXQ];
-    {
-        unsigned long long mm = head_m;
-#pragma unroll
-        for (int q = 0; q < MAXQ; q++) {
-            const int l = mm ? (int) __ffsll((long long) mm) - 1 : 0;
-            pixq[q]     = (mm && few) ? __builtin_amdgcn_readlane(pix, l) : -1;
-            outq[q]     = 0.0;
-            mm &= mm - 1;
-        }
-    }
 
     // ---- the march record of this lane's ray ---------------------------------------
     float gs[SF ? SF : 1], es[SF ? SF : 1];
@@ -266,84 +239,110 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     double angsum = 0.0;
     bool bad_neg = false, bad_nan = false;
     double *img_row = P.image + (size_t) (pix >= 0 ? pix : 0) * (size_t) K;
-    for (int kb = 0; kb < K; kb += VEC) {
-        double Iv[VEC];
-        if (use_emis) {
+
+    // The frequency loop, instantiated once per deposit mode (exclusive / few runs / row
+    // cache / segmented scan) so that each instance keeps only its own deposit state in
+    // registers: `deposit(kb, j, v)` consumes one value, `window_end(kb)` closes a batch.
+    auto frequency_loop = [&](auto deposit, auto window_end) {
+        for (int kb = 0; kb < K; kb += VEC) {
+            double Iv[VEC];
+            if (use_emis) {
 #pragma unroll
-            for (int j = 0; j < VEC; j++)
-                Iv[j] = 0.0;
-            if (SF) {
-                FVec<VEC> w[SF ? SF : 1];
+                for (int j = 0; j < VEC; j++)
+                    Iv[j] = 0.0;
+                if (SF) {
+                    FVec<VEC> w[SF ? SF : 1];
 #pragma unroll
-                for (int s = 0; s < SF; s++) {
+                    for (int s = 0; s < SF; s++) {
 #ifdef RT_ABL_NOLOAD
-                    const float *row = P.gain[s / RT_N_SUB + 1].gv + kb;
+                        const float *row = P.gain[s / RT_N_SUB + 1].gv + kb;
 #else
-                    const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) K + kb;
+                        const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) K + kb;
 #endif
-                    w[s]             = *reinterpret_cast<const FVec<VEC> *>(row);
-                }
+                        w[s] = *reinterpret_cast<const FVec<VEC> *>(row);
+                    }
 #pragma unroll
-                for (int s = 0; s < SF; s++) {
-                    if (gs[s] != 0.0f || es[s] != 0.0f) { // else the update is the identity
+                    for (int s = 0; s < SF; s++) {
+                        if (gs[s] != 0.0f || es[s] != 0.0f) { // else the update is the identity
 #pragma unroll
-                        for (int j = 0; j < VEC; j++)
-                            Iv[j] = ase_update(Iv[j], gs[s], es[s], w[s].v[j], tab);
+                            for (int j = 0; j < VEC; j++)
+                                Iv[j] = ase_update(Iv[j], gs[s], es[s], w[s].v[j], tab);
+                        }
+                    }
+                } else {
+                    for (int s = 0; s < S; s++) {
+                        const float g1 = reinterpret_cast<const float *>(rec)[s];
+                        const float e1 = reinterpret_cast<const float *>(rec)[S + s];
+                        const int c1   = reinterpret_cast<const int *>(rec)[2 * S + s];
+                        if (g1 != 0.0f || e1 != 0.0f) {
+                            const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
+                            const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+#pragma unroll
+                            for (int j = 0; j < VEC; j++)
+                                Iv[j] = ase_update(Iv[j], g1, e1, w.v[j], tab);
+                        }
                     }
                 }
             } else {
-                for (int s = 0; s < S; s++) {
-                    const float g1 = reinterpret_cast<const float *>(rec)[s];
-                    const float e1 = reinterpret_cast<const float *>(rec)[S + s];
-                    const int c1   = reinterpret_cast<const int *>(rec)[2 * S + s];
-                    if (g1 != 0.0f || e1 != 0.0f) {
-                        const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
-                        const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
-#pragma unroll
-                        for (int j = 0; j < VEC; j++)
-                            Iv[j] = ase_update(Iv[j], g1, e1, w.v[j], tab);
-                    }
-                }
-            }
-        } else {
-            // gain only, Helper.h:569-580: f64 products summed in sub-segment order
-            double gl[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; j++)
-                gl[j] = 0.0;
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                const float g1    = SF ? gs[SF ? s : 0] : reinterpret_cast<const float *>(rec)[s];
-                const int c1      = SF ? cs[SF ? s : 0] : reinterpret_cast<const int *>(rec)[2 * S + s];
-                const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
-                const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+                // gain only, Helper.h:569-580: f64 products summed in sub-segment order
+                double gl[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; j++)
-                    gl[j] += (double) g1 * (double) w.v[j];
+                    gl[j] = 0.0;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const float g1    = SF ? gs[SF ? s : 0] : reinterpret_cast<const float *>(rec)[s];
+                    const int c1      = SF ? cs[SF ? s : 0] : reinterpret_cast<const int *>(rec)[2 * S + s];
+                    const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
+                    const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+#pragma unroll
+                    for (int j = 0; j < VEC; j++)
+                        gl[j] += (double) g1 * (double) w.v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    Iv[j] = f0 * P.seed.f[4][kb + j];
+                    // 0 * exp(gl) is exactly 0 unless exp overflows: skip the exp then
+                    if (f0 != 0.0 || gl[j] > 700.0)
+                        Iv[j] *= (gl[j] != gl[j]) ? gl[j] : exp_tab(gl[j], tab);
+                }
             }
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-                Iv[j] = f0 * P.seed.f[4][kb + j];
-                // 0 * exp(gl) is exactly 0 unless exp overflows: skip the exp then
-                if (f0 != 0.0 || gl[j] > 700.0)
-                    Iv[j] *= (gl[j] != gl[j]) ? gl[j] : exp_tab(gl[j], tab);
+                const double iv = live ? Iv[j] : 0.0;
+                bad_neg         = bad_neg || iv < 0.0; // Helper.h:582-594
+                bad_nan         = bad_nan || iv != iv;
+                angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
+                // RayTraceImageCPU.cpp:59, summed over the run of rays that share the pixel
+                deposit(kb, j, pix >= 0 ? iv * P.scale : 0.0);
             }
+            window_end(kb);
         }
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-            const double iv = live ? Iv[j] : 0.0;
-            bad_neg         = bad_neg || iv < 0.0; // Helper.h:582-594
-            bad_nan         = bad_nan || iv != iv;
-            angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
-            // RayTraceImageCPU.cpp:59, summed over the run of rays that share the pixel
-            double v = pix >= 0 ? iv * P.scale : 0.0;
-            if (excl_all) {
-                // one ray per pixel: plain stores of the row, no reduction, no atomics
+    };
+
+    if (excl_all) {
+        // one ray per pixel: plain stores of the row, no reduction, no atomics
+        frequency_loop(
+            [&](int kb, int j, double v) {
                 if (own_pix >= 0)
                     P.image[(size_t) own_pix * (size_t) K + (size_t) (kb + j)] = (pix == own_pix) ? v : 0.0;
                 if (pix >= 0 && pix != own_pix)
                     unsafeAtomicAdd(&img_row[kb + j], v);
-            } else if (few) {
+            },
+            [&](int) {});
+    } else if (few) {
+        int pixq[MAXQ];
+        double outq[MAXQ];
+        unsigned long long mm = head_m;
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int l = mm ? (int) __ffsll((long long) mm) - 1 : 0;
+            pixq[q]     = mm ? __builtin_amdgcn_readlane(pix, l) : -1;
+            outq[q]     = 0.0;
+            mm &= mm - 1;
+        }
+        frequency_loop(
+            [&](int kb, int j, double v) {
 #pragma unroll
                 for (int q = 0; q < MAXQ; q++) {
                     if (pixq[q] >= 0) {
@@ -353,31 +352,53 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                             outq[q] += sum;
                     }
                 }
-            } else if (cached) {
+            },
+            [&](int kb) {
+                if ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K) {
+                    // flush the window of 64 frequencies that ends here
+                    const int kw = (kb + VEC - 1) & ~(WAVE - 1);
+                    const int k  = kw + lane;
+#pragma unroll
+                    for (int q = 0; q < MAXQ; q++) {
+                        if (pixq[q] >= 0 && k < K)
+                            unsafeAtomicAdd(&P.image[(size_t) pixq[q] * (size_t) K + (size_t) k], outq[q]);
+                        outq[q] = 0.0;
+                    }
+                }
+            });
+    } else if (cached) {
+        double *my_row = cache + (size_t) run_id * (size_t) K;
+        frequency_loop(
+            [&](int kb, int j, double v) {
                 if (pix >= 0)
-                    unsafeAtomicAdd(&cache[run_id * K + kb + j], v);
-            } else {
+                    unsafeAtomicAdd(&my_row[kb + j], v);
+            },
+            [&](int) {});
+    } else {
+        // segmented shuffle scan over the runs, one atomic per run and frequency
+        const int pix_prev = __shfl_up(pix, 1, WAVE);
+        const bool head    = lane == 0 || pix_prev != pix;
+        int run_start      = head ? lane : -1;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int t = __shfl_up(run_start, o, WAVE);
+            if (lane >= o && t > run_start)
+                run_start = t;
+        }
+        const int head_next = __shfl_down(head ? 1 : 0, 1, WAVE);
+        const bool tail     = (lane == WAVE - 1 || head_next != 0) && pix >= 0;
+        frequency_loop(
+            [&](int kb, int j, double v) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double t = __shfl_up(v, 1 << i, WAVE);
-                    if (addm[i])
+                    if ((lane - (1 << i)) >= run_start)
                         v += t;
                 }
                 if (tail)
                     unsafeAtomicAdd(&img_row[kb + j], v);
-            }
-        }
-        if (few && !excl_all && ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K)) {
-            // flush the window of 64 frequencies that ends here
-            const int kw = (kb + VEC - 1) & ~(WAVE - 1);
-            const int k  = kw + lane;
-#pragma unroll
-            for (int q = 0; q < MAXQ; q++) {
-                if (pixq[q] >= 0 && k < K)
-                    unsafeAtomicAdd(&P.image[(size_t) pixq[q] * (size_t) K + (size_t) k], outq[q]);
-                outq[q] = 0.0;
-            }
-        }
+            },
+            [&](int) {});
     }
     if (cached) {
         // flush this tile's rows: one coalesced run of atomics per pixel run, rows re-zeroed

@@ -186,13 +186,16 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     const int in_lds       = ang_bytes <= 32 * 1024;
     // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K
     // doubles, at most 10 KB per wave; fewer than 4 rows is not worth having
-    int nslot = (int) ((10 * 1024) / ((size_t) p->P.K * sizeof(double)));
+    int nslot = (int) ((8 * 1024 + 512) / ((size_t) p->P.K * sizeof(double)));
     nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
     const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
-    int per_cu             = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_freq_kernel<SF, VEC>, 256, lds));
-    if (per_cu < 1)
-        per_cu = 1;
+    // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
+    // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
+    // (surplus work-groups find the tile counter exhausted and leave)
+    int per_cu = (int) ((160 * 1024) / (lds + 1024));
+    per_cu     = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    if (const char *e = getenv("RT_HIP_FREQ_WGS")) // tuning override
+        per_cu = atoi(e);
     unsigned long long want = ((unsigned long long) p->P.n_tiles + 3) / 4;
     unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
     if (cap_blocks && cap > cap_blocks)
