@@ -136,7 +136,9 @@ struct DevParams {
     float *path;   // [n_rays][3 (N-1) + 1][3] = {x, y, I} triples, the reference's debug layout
     int32_t *path_err; // [n_rays] return code of each ray
     // step safety factor c of Helper.h:270-313 folded into its three uses (c = 0.5 in create_image)
-    float c_cap, c_h1, c_h3, pad4; // c*1.00001f, c*0.1f, c*0.05f
+    float c_cap, c_h1, c_h3, gs_cap; // c*1.00001f, c*0.1f, c*0.05f; see below
+    // gs_cap = 708 / max |gv|: per-sub-segment gain sums are clamped to it before the frequency
+    // pass, so that gs * gv never leaves the range where e^x is a normal double (rt_freq.hip)
 };
 
 // flag bits of the per-ray march record

@@ -21,7 +21,7 @@
 namespace rt {
 
 #ifndef RT_FREQ_WAVES
-#define RT_FREQ_WAVES 4 // waves per SIMD the frequency kernel is compiled for (<= 128 VGPRs)
+#define RT_FREQ_WAVES 3 // waves per SIMD the frequency kernel is compiled for (<= 168 VGPRs; 4 spills)
 #endif
 
 template <int VEC> struct FVec;
@@ -87,7 +87,8 @@ __device__ __forceinline__ double wave_total_lane63(double v)
     return v;
 }
 
-// Helper.h:549-557, one (sub-segment, frequency) update with emission
+// Helper.h:549-557, one (sub-segment, frequency) update with emission, as the CPU writes it
+// (kept for the sub-segments whose gain sum is zero or denormal-small, see ase_step)
 __device__ __forceinline__ double ase_update(double Iv, float gs, float es, float w, const double *tab)
 {
     const double gl = (double) (gs * w); // f32 product, then widened (Helper.h:549-550)
@@ -97,6 +98,56 @@ __device__ __forceinline__ double ase_update(double Iv, float gs, float es, floa
     const double eg = exp_tab(gl, tab);
     return div_fast(el, gl) * (eg - 1.0) + Iv * eg;
 }
+
+// The same update in the form the kernel runs for every regular sub-segment:
+//     Iv' = (el/gl) (e^gl - 1) + Iv e^gl  =  Iv + (e^gl - 1) (Iv + rs),   rs = es/gs,
+// with gl = (double)(gs*w) exactly as the CPU rounds it (the exponent is where rounding of gl
+// matters) and rs taken once per sub-segment: el/gl = fl(es w)/fl(gs w) = rs (1 + d), |d| <
+// 1.2e-7, a float rounding of the two products that the 1e-5 gate does not resolve.
+// e^gl - 1 is built without cancellation from gl = (64 m + j) ln2/64 + r:
+//     S = 2^m 2^(j/64),  e^r - 1 = r Q(r),  e^gl - 1 = (S - 1) + S r Q(r),
+// so one branch-free sequence covers |gl| < 1e-3 (where the CPU switches to a cubic whose
+// own truncation, gl^3/24, is 4e-11) as well as large gains.  The caller keeps |gs * w|
+// <= 708 (DevParams::gs_cap): e^gl stays a normal double, S is assembled by an integer add
+// into the exponent field, and the reduction needs one constant (|64 m + j| < 2^16, so the
+// rounding of ln2/64 moves r by < 6e-14).  A NaN lineshape value gives garbage here; the
+// caller tests for it.  VEC independent chains, table reads issued together.
+template <int VEC>
+__device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, const double rs, const float (&w)[VEC],
+                                         const double *tab)
+{
+    const double L2E64 = 92.33248261689366;  // 64 / ln 2
+    const double LN2_64 = 0.010830424696249145; // ln 2 / 64
+    const double MAGIC = 0x1.8p52;           // adding it leaves rint(.) in the low mantissa bits
+    double r[VEC], T[VEC];
+    int m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const double x = (double) (gs * w[j]);
+        double t       = fma(x, L2E64, MAGIC);
+        const int n    = __double2loint(t);
+        t -= MAGIC;
+        r[j] = fma(-t, LN2_64, x);
+        T[j] = tab[n & 63];
+        m[j] = n >> 6;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        double q = fma(r[j], 1.0 / 120.0, 1.0 / 24.0);
+        q        = fma(r[j], q, 1.0 / 6.0);
+        q        = fma(r[j], q, 0.5);
+        q        = fma(r[j], q, 1.0);
+        int hi; // exponent field += m in one v_lshl_add_u32 (the compiler's own choice is shift, mask, add)
+        asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"(m[j]), "v"(__double2hiint(T[j])));
+        const double S   = __hiloint2double(hi, __double2loint(T[j]));
+        const double em1 = fma(S, r[j] * q, S - 1.0);
+        Iv[j]            = fma(em1, Iv[j] + rs, Iv[j]);
+    }
+}
+
+// gain sums below this magnitude (or NaN) take the CPU's own formula: es/gs would overflow
+// or the float product gs*w would underflow where es*w does not
+#define RT_RS_MIN 1e-30f
 
 // uniform-grid shortcut of deposit_index (RayTraceImageCPU.cpp:11-16): the grids
 // of the beam are uniform (create_image checks it); guess the cell arithmetically,
@@ -122,10 +173,17 @@ __device__ __forceinline__ int deposit_index_fast(int n, const double *g, double
     return first_not_below(g, n, t);
 }
 
+// per-wave LDS scratch of the few-runs deposit: [4][XP_ROW] transposition rows (row stride
+// 66 doubles: 16-byte aligned, rows 4 banks apart) + [FREQ_MAXQ][64] window totals
+constexpr int XP_ROW          = 66;
+constexpr int FREQ_MAXQ       = 3;
+constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
+
 template <int SF, int VEC>
-__device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const double *tab,
+__device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const double *tab, double *xpose,
                                           double *cache, const int nslot, const unsigned tile, const int lane)
 {
+    double *win = xpose + 4 * XP_ROW; // [MAXQ][64] totals of the current window of 64 frequencies
     const int S           = SF ? SF : P.L * RT_N_SUB;
     const int K           = P.K;
     const unsigned n_rays = (unsigned) P.rays.count;
@@ -215,7 +273,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     // row of the wave's LDS row cache [nslot][K]; lanes add into their run's row with LDS f64
     // atomics, rows are flushed per tile with coalesced atomics.  Beyond the cache: a
     // segmented shuffle scan.
-    constexpr int MAXQ               = 3;
+    constexpr int MAXQ               = FREQ_MAXQ;
     const int pix_before             = __shfl_up(pix, 1, WAVE);
     const unsigned long long head_m  = __ballot(lane == 0 || pix_before != pix);
     const int n_runs                 = (int) __popcll(head_m);
@@ -225,14 +283,18 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     const int run_id                 = (int) __popcll(head_m & le_mask) - 1;
 
     // ---- the march record of this lane's ray ---------------------------------------
-    float gs[SF ? SF : 1], es[SF ? SF : 1];
+    float gs[SF ? SF : 1];
+    double rs[SF ? SF : 1]; // es/gs, the source function of the sub-segment (see ase_step)
     int cs[SF ? SF : 1];
     if (SF) {
 #pragma unroll
         for (int s = 0; s < SF; s++) {
-            gs[s] = reinterpret_cast<const float *>(rec)[s];
-            es[s] = reinterpret_cast<const float *>(rec)[SF + s];
-            cs[s] = reinterpret_cast<const int *>(rec)[2 * SF + s];
+            gs[s]          = reinterpret_cast<const float *>(rec)[s];
+            const float e1 = reinterpret_cast<const float *>(rec)[SF + s];
+            cs[s]          = reinterpret_cast<const int *>(rec)[2 * SF + s];
+            rs[s]          = fabsf(gs[s]) >= RT_RS_MIN ? div_fast((double) e1, (double) gs[s]) : 0.0;
+            if (use_emis && fabsf(gs[s]) >= RT_RS_MIN)
+                gs[s] = __builtin_amdgcn_fmed3f(gs[s], -P.gs_cap, P.gs_cap); // keeps |gs * gv| <= 708
         }
     }
 
@@ -242,14 +304,17 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 
     // The frequency loop, instantiated once per deposit mode (exclusive / few runs / row
     // cache / segmented scan) so that each instance keeps only its own deposit state in
-    // registers: `deposit(kb, j, v)` consumes one value, `window_end(kb)` closes a batch.
-    auto frequency_loop = [&](auto deposit, auto window_end) {
+    // registers: `deposit(kb, v)` consumes the lane's values of frequencies kb .. kb+VEC-1.
+    auto frequency_loop = [&](auto deposit) {
         for (int kb = 0; kb < K; kb += VEC) {
             double Iv[VEC];
             if (use_emis) {
+                bool wnan[VEC]; // a NaN anywhere in this frequency's lineshape values (0 * NaN on the CPU)
 #pragma unroll
-                for (int j = 0; j < VEC; j++)
-                    Iv[j] = 0.0;
+                for (int j = 0; j < VEC; j++) {
+                    Iv[j]   = 0.0;
+                    wnan[j] = false;
+                }
                 if (SF) {
                     FVec<VEC> w[SF ? SF : 1];
 #pragma unroll
@@ -263,10 +328,18 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     }
 #pragma unroll
                     for (int s = 0; s < SF; s++) {
-                        if (gs[s] != 0.0f || es[s] != 0.0f) { // else the update is the identity
 #pragma unroll
-                            for (int j = 0; j < VEC; j++)
-                                Iv[j] = ase_update(Iv[j], gs[s], es[s], w[s].v[j], tab);
+                        for (int j = 0; j < VEC; j++)
+                            wnan[j] = wnan[j] || w[s].v[j] != w[s].v[j];
+                        if (fabsf(gs[s]) >= RT_RS_MIN) {
+                            ase_step<VEC>(Iv, gs[s], rs[s], w[s].v, tab);
+                        } else {
+                            const float e1 = reinterpret_cast<const float *>(rec)[SF + s];
+                            if (gs[s] != 0.0f || e1 != 0.0f) { // else the update is the identity
+#pragma unroll
+                                for (int j = 0; j < VEC; j++)
+                                    Iv[j] = ase_update(Iv[j], gs[s], e1, w[s].v[j], tab);
+                            }
                         }
                     }
                 } else {
@@ -274,15 +347,24 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         const float g1 = reinterpret_cast<const float *>(rec)[s];
                         const float e1 = reinterpret_cast<const float *>(rec)[S + s];
                         const int c1   = reinterpret_cast<const int *>(rec)[2 * S + s];
-                        if (g1 != 0.0f || e1 != 0.0f) {
-                            const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
-                            const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+                        const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
+                        const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+#pragma unroll
+                        for (int j = 0; j < VEC; j++)
+                            wnan[j] = wnan[j] || w.v[j] != w.v[j];
+                        if (fabsf(g1) >= RT_RS_MIN) {
+                            const double r1 = div_fast((double) e1, (double) g1);
+                            ase_step<VEC>(Iv, __builtin_amdgcn_fmed3f(g1, -P.gs_cap, P.gs_cap), r1, w.v, tab);
+                        } else if (g1 != 0.0f || e1 != 0.0f) {
 #pragma unroll
                             for (int j = 0; j < VEC; j++)
                                 Iv[j] = ase_update(Iv[j], g1, e1, w.v[j], tab);
                         }
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
+                    Iv[j] = wnan[j] ? __builtin_nan("") : Iv[j];
             } else {
                 // gain only, Helper.h:569-580: f64 products summed in sub-segment order
                 double gl[VEC];
@@ -314,66 +396,108 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                 bad_nan         = bad_nan || iv != iv;
                 angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
                 // RayTraceImageCPU.cpp:59, summed over the run of rays that share the pixel
-                deposit(kb, j, pix >= 0 ? iv * P.scale : 0.0);
+                Iv[j] = pix >= 0 ? iv * P.scale : 0.0;
             }
-            window_end(kb);
+#ifndef RT_ABL_NODEPOSIT
+            deposit(kb, Iv);
+#endif
         }
     };
 
+#ifdef RT_ABL_ONLY_FEW
+    if (false) {
+#else
     if (excl_all) {
+#endif
         // one ray per pixel: plain stores of the row, no reduction, no atomics
-        frequency_loop(
-            [&](int kb, int j, double v) {
+        frequency_loop([&](int kb, double (&v)[VEC]) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
                 if (own_pix >= 0)
-                    P.image[(size_t) own_pix * (size_t) K + (size_t) (kb + j)] = (pix == own_pix) ? v : 0.0;
+                    P.image[(size_t) own_pix * (size_t) K + (size_t) (kb + j)] = (pix == own_pix) ? v[j] : 0.0;
                 if (pix >= 0 && pix != own_pix)
-                    unsafeAtomicAdd(&img_row[kb + j], v);
-            },
-            [&](int) {});
+                    unsafeAtomicAdd(&img_row[kb + j], v[j]);
+            }
+        });
+#ifdef RT_ABL_ONLY_FEW
+    } else if (true) {
+#else
     } else if (few) {
+#endif
+        // Per run and frequency one sum over the wave.  VEC = 4: the lanes park their four
+        // values in the wave's LDS scratch [4][XP_ROW], lane (j, p) = (lane / 16, lane % 16)
+        // adds four neighbours of frequency j, a row_shr tree inside the row of 16 lanes
+        // finishes the sum (15 VALU operations for 4 frequencies instead of 4 x 18 for four
+        // full-wave DPP trees).  Totals wait in the LDS window win[run][k mod 64] and leave
+        // as one coalesced atomic per run and 64 frequencies.
         int pixq[MAXQ];
-        double outq[MAXQ];
         unsigned long long mm = head_m;
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
             const int l = mm ? (int) __ffsll((long long) mm) - 1 : 0;
             pixq[q]     = mm ? __builtin_amdgcn_readlane(pix, l) : -1;
-            outq[q]     = 0.0;
             mm &= mm - 1;
         }
-        frequency_loop(
-            [&](int kb, int j, double v) {
+        const bool single = n_runs == 1;
+        auto wave_sums    = [&](const int q, const int kb, double (&v)[VEC], const bool masked) {
+#ifdef RT_ABL_DPP
+            if (false) {
+#else
+            if (VEC == 4) {
+#endif
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
+                    xpose[j * XP_ROW + lane] = (!masked || run_id == q) ? v[j] : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                const double *src = xpose + (lane >> 4) * XP_ROW + 4 * (lane & 15);
+                double t          = (src[0] + src[1]) + (src[2] + src[3]);
+                __builtin_amdgcn_wave_barrier();
+                t = dpp_step<0x111, 0xf>(t);
+                t = dpp_step<0x112, 0xf>(t);
+                t = dpp_step<0x114, 0xf>(t);
+                t = dpp_step<0x118, 0xf>(t);
+                if ((lane & 15) == 15)
+                    win[q * WAVE + ((kb + (lane >> 4)) & (WAVE - 1))] = t;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const double t = wave_total_lane63((!masked || run_id == q) ? v[j] : 0.0);
+                    if (lane == WAVE - 1)
+                        win[q * WAVE + ((kb + j) & (WAVE - 1))] = t;
+                }
+            }
+        };
+        frequency_loop([&](int kb, double (&v)[VEC]) {
+            if (single) {
+                wave_sums(0, kb, v, false);
+            } else {
 #pragma unroll
                 for (int q = 0; q < MAXQ; q++) {
-                    if (pixq[q] >= 0) {
-                        const double tot = wave_total_lane63(run_id == q ? v : 0.0);
-                        const double sum = readlane_f64(tot, WAVE - 1);
-                        if (lane == ((kb + j) & (WAVE - 1)))
-                            outq[q] += sum;
-                    }
+                    if (pixq[q] >= 0)
+                        wave_sums(q, kb, v, true);
                 }
-            },
-            [&](int kb) {
-                if ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K) {
-                    // flush the window of 64 frequencies that ends here
-                    const int kw = (kb + VEC - 1) & ~(WAVE - 1);
-                    const int k  = kw + lane;
+            }
+            if ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K) {
+                // flush the window of 64 frequencies that ends here
+                __builtin_amdgcn_wave_barrier();
+                const int k = ((kb + VEC - 1) & ~(WAVE - 1)) + lane;
 #pragma unroll
-                    for (int q = 0; q < MAXQ; q++) {
-                        if (pixq[q] >= 0 && k < K)
-                            unsafeAtomicAdd(&P.image[(size_t) pixq[q] * (size_t) K + (size_t) k], outq[q]);
-                        outq[q] = 0.0;
-                    }
+                for (int q = 0; q < MAXQ; q++) {
+                    if (pixq[q] >= 0 && k < K)
+                        unsafeAtomicAdd(&P.image[(size_t) pixq[q] * (size_t) K + (size_t) k], win[q * WAVE + lane]);
                 }
-            });
+                __builtin_amdgcn_wave_barrier();
+            }
+        });
     } else if (cached) {
         double *my_row = cache + (size_t) run_id * (size_t) K;
-        frequency_loop(
-            [&](int kb, int j, double v) {
+        frequency_loop([&](int kb, double (&v)[VEC]) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
                 if (pix >= 0)
-                    unsafeAtomicAdd(&my_row[kb + j], v);
-            },
-            [&](int) {});
+                    unsafeAtomicAdd(&my_row[kb + j], v[j]);
+            }
+        });
     } else {
         // segmented shuffle scan over the runs, one atomic per run and frequency
         const int pix_prev = __shfl_up(pix, 1, WAVE);
@@ -387,18 +511,20 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         }
         const int head_next = __shfl_down(head ? 1 : 0, 1, WAVE);
         const bool tail     = (lane == WAVE - 1 || head_next != 0) && pix >= 0;
-        frequency_loop(
-            [&](int kb, int j, double v) {
+        frequency_loop([&](int kb, double (&v)[VEC]) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                double a = v[j];
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
-                    const double t = __shfl_up(v, 1 << i, WAVE);
+                    const double t = __shfl_up(a, 1 << i, WAVE);
                     if ((lane - (1 << i)) >= run_start)
-                        v += t;
+                        a += t;
                 }
                 if (tail)
-                    unsafeAtomicAdd(&img_row[kb + j], v);
-            },
-            [&](int) {});
+                    unsafeAtomicAdd(&img_row[kb + j], a);
+            }
+        });
     }
     if (cached) {
         // flush this tile's rows: one coalesced run of atomics per pixel run, rows re-zeroed
@@ -436,6 +562,7 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double exp2_tab[64]; // 2^(j/64), j = 0..63
+    __shared__ __align__(16) double xpose_wg[4 * FREQ_WAVE_XPOSE];
     double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
     const int n_ang  = P.beam.na * P.beam.nb;
     double *cache_wg = reinterpret_cast<double *>(lds_raw) + (iang_in_lds ? n_ang : 0);
@@ -457,7 +584,7 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
         tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
         if (tile >= P.n_tiles)
             break;
-        freq_tile<SF, VEC>(P, lds_iang, exp2_tab, cache, nslot, tile, lane);
+        freq_tile<SF, VEC>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
     }
     if (lds_iang) {
         __syncthreads();

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cfloat>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -179,20 +180,27 @@ struct rt_hip_plan {
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
 // the shipped inputs; 0 = any N), VEC = frequencies per lane per pass
+#ifndef RT_ABL_VEC2
+#define RT_ABL_VEC2 0 // profiling only: 2 frequencies per pass where 4 would do
+#endif
+
 template <int SF, int VEC>
 static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
     const int in_lds       = ang_bytes <= 32 * 1024;
     // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K
-    // doubles, at most 10 KB per wave; fewer than 4 rows is not worth having
-    int nslot = (int) ((8 * 1024 + 512) / ((size_t) p->P.K * sizeof(double)));
+    // doubles in at most 5 KB per wave -- with the static scratch (transposition rows, exp
+    // table) and the I_ang histogram that leaves room for the four work-groups per CU the
+    // register budget allows; fewer than 4 rows is not worth having
+    int nslot = (int) ((5 * 1024) / ((size_t) p->P.K * sizeof(double)));
     nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
-    const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
+    const size_t lds      = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
+    const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + 64 * sizeof(double);
     // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
     // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
     // (surplus work-groups find the tile counter exhausted and leave)
-    int per_cu = (int) ((160 * 1024) / (lds + 1024));
+    int per_cu = (int) ((160 * 1024) / (lds + lds_stat + 512));
     per_cu     = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     if (const char *e = getenv("RT_HIP_FREQ_WGS")) // tuning override
         per_cu = atoi(e);
@@ -280,7 +288,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         const int S = p->P.L * RT_N_SUB, K = p->P.K;
         int rc;
         if (S == 6) {
-            rc = (K % 4 == 0) ? launch_freq<6, 4>(p, stream, 0)
+            rc = (K % 4 == 0 && !RT_ABL_VEC2) ? launch_freq<6, 4>(p, stream, 0)
                               : (K % 2 == 0 ? launch_freq<6, 2>(p, stream, 0) : launch_freq<6, 1>(p, stream, 0));
         } else {
             rc = (K % 4 == 0) ? launch_freq<0, 4>(p, stream, 0)
@@ -530,6 +538,21 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     P.c_cap      = 0.5f * 1.00001f; // step safety factor c = 0.5 (Helper.h:381), see rt_hip_plan_set_step_factor
     P.c_h1       = 0.5f * 0.1f;
     P.c_h3       = 0.5f * 0.05f;
+    {
+        // largest finite |lineshape value| of the planes the frequency pass reads
+        float wmax = 0.0f;
+        for (int i = 1; i < N; i++) {
+            const size_t n = (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K;
+            for (size_t c = 0; c < n; c++) {
+                const float a = fabsf(gain[i].gv[c]);
+                if (a > wmax && a <= FLT_MAX)
+                    wmax = a;
+            }
+        }
+        P.gs_cap = wmax > 0.0f ? 708.0f / wmax : FLT_MAX;
+        if (!(P.gs_cap <= FLT_MAX))
+            P.gs_cap = FLT_MAX;
+    }
     P.ctl = p->ctl;
     *out  = p;
     return RT_OK;

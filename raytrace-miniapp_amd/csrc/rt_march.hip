@@ -64,6 +64,12 @@ __device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray
     }
 }
 
+// Wide-argument fallbacks of the two float kernels below.  Kept out of line: inlined, the
+// double-precision libm bodies park ~40 VGPRs of polynomial coefficients across the whole
+// calling kernel for a branch that the shipped inputs never take.
+__device__ __attribute__((noinline)) float tan_wide(float x) { return (float) tan((double) x); }
+__device__ __attribute__((noinline)) float atan_wide(float x) { return (float) atan((double) x); }
+
 // tanf as the reference's libm computes it.  Helper.h:409-410 calls tanf(1e-3f * a); on
 // the reference platform that is GNU libc 2.35, sysdeps/ieee754/flt-32/{s,k}_tanf.c --
 // the fdlibm float kernel: for |x| < 0.6744 a degree-13 odd polynomial evaluated in float
@@ -77,7 +83,7 @@ __device__ __forceinline__ float tanf_flt32_kernel(float x)
     if (ax < 0x1p-13f) // s_tanf.c/k_tanf.c: (int) x == 0 -> return x
         return x;
     if (ax > 0.2f)
-        return (float) tan((double) x);
+        return tan_wide(x);
     const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
                 T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
                 T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,
@@ -101,7 +107,7 @@ __device__ __forceinline__ float atanf_flt32_kernel(float x)
     if (ax < 0x1p-29f)
         return x;
     if (!(ax < 0.4375f))
-        return (float) atan((double) x);
+        return atan_wide(x);
     const float A0 = 3.3333334327e-01f, A1 = -2.0000000298e-01f, A2 = 1.4285714924e-01f, A3 = -1.1111110449e-01f,
                 A4 = 9.0908870101e-02f, A5 = -7.6918758452e-02f, A6 = 6.6610731184e-02f, A7 = -5.8335702866e-02f,
                 A8 = 4.9768779427e-02f, A9 = -3.6531571299e-02f, A10 = 1.6285819933e-02f;

@@ -68,6 +68,6 @@ def test_exclusive_pixel_mode_equals_atomic_mode(hip, oracle, ase_small):
         b = plan.set_rays(p.build_rays()).run().fetch()
     ref = oracle.image_loop(p, n_threads=4)
     assert np.array_equal(a["image"], a2["image"])
-    assert rel_l2(a["image"], ref["image"]) < 1e-11 and rel_l2(b["image"], ref["image"]) < 1e-11
-    assert rel_l2(a["I_ang"], ref["I_ang"]) < 1e-11
+    assert rel_l2(a["image"], ref["image"]) < 2e-7 and rel_l2(b["image"], ref["image"]) < 2e-7
+    assert rel_l2(a["I_ang"], ref["I_ang"]) < 2e-7
     assert (a["image"] == 0).reshape(-1, 128).all(axis=1).sum() == (ref["image"] == 0).reshape(-1, 128).all(axis=1).sum()

@@ -3,7 +3,10 @@
 Tolerances: the march record (gvl, evl, ivl, flags, cell-steps) is integer /
 float32 work reproduced bit for bit; image and I_ang are float64 sums whose
 order differs (atomics, shuffle tree) and whose exp() comes from a different
-libm: gate 1e-5 rel-L2 (BASELINE.json north_star), expected ~1e-14.
+libm: gate 1e-5 rel-L2 (BASELINE.json north_star).  Expected: ~1e-8 with emission
+(the kernel takes the source function es/gs once per sub-segment where the CPU
+divides two float32 products per frequency: relative difference < 1.2e-7 per term),
+~1e-14 in the seeded gain-only mode.
 """
 import importlib
 
@@ -16,7 +19,7 @@ rt = importlib.import_module("raytrace-miniapp_amd")
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5          # north_star gate
-TOL_TIGHT = 1e-11   # what f64 reordering + libm differences actually allow
+TOL_TIGHT = 2e-7    # one float rounding of es/gs per sub-segment (frequency kernel); seeded gain-only mode stays ~1e-14
 
 
 def _check_probe(hip_probe, ora):
