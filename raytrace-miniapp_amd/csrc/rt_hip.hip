@@ -851,8 +851,8 @@ int rt_hip_plan_kernel_times(rt_hip_plan *p, float *march_ms, float *freq_ms)
     return RT_OK;
 }
 
-#ifdef RT_INSTRUMENT
-// diagnostic build only: read and clear the loop-occupancy counters
+#if defined(RT_INSTRUMENT) || defined(RT_TIMEBLOCKS)
+// diagnostic builds only: read and clear the loop-occupancy / block-clock counters
 int rt_hip_debug_counters(unsigned long long *out8)
 {
     HIP_TRY(hipDeviceSynchronize());

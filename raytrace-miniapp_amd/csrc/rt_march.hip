@@ -214,7 +214,14 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     Inst inst;
 #endif
 
+#ifdef RT_TIMEBLOCKS
+    unsigned long long tb_acc[6] = { 0, 0, 0, 0, 0, 0 }, tb_last = __builtin_readcyclecounter(), tb_iters = 0;
+#endif
     for (;;) {
+        RT_MARK(5); // [C] of the previous iteration
+#ifdef RT_TIMEBLOCKS
+        tb_iters++;
+#endif
         // ------------------------------------------------------------ refill
         const unsigned long long idle = __ballot(st == ST_IDLE);
         const int n_idle              = (int) __popcll(idle);
@@ -287,9 +294,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         if (__ballot(st != ST_IDLE) == 0ull) {
             if (!more)
                 break;
-            continue;
-        }
+        } else {
 
+        RT_MARK(0); // refill
         // ------------------------------------------------------------ [A] cell loop (Helper.h:430-504)
         // Straight-line: at most one sub-segment end [A1] and one cell setup [A2] per wave
         // iteration (a lane that needs more -- several empty sub-segments in a row, or the
@@ -345,6 +352,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     }
                 }
             }
+            RT_MARK(1); // [A1]
             if ((st == ST_CELL) & in_seg) {
                 // [A2] escape test + cell setup (Helper.h:465-497)
                 const BlobGain G = hdr[ii];
@@ -403,6 +411,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     }
                 }
             }
+            RT_MARK(2); // [A2]
             // ---------------------------------------------------------- ray finished
             if (st == ST_DONE) {
                 unsigned fl = F_VALID;
@@ -426,6 +435,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             }
         }
 
+        RT_MARK(3); // DONE
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
             const double n00 = *reinterpret_cast<const double *>(tab + node_off);
@@ -454,6 +464,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             RT_TICK(1);
         }
 
+        RT_MARK(4); // [B]
         // ------------------------------------------------------------ [C] one integrator step (Helper.h:279-311)
         if (st == ST_STEP) {
             const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
@@ -461,16 +472,21 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             bool run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & (fabsf(n - n0) < 0.05f);
             if (run) {
                 n        = n0 + rx * gxn + ry * gyn;
-                const float rn = 1.0f / n; // one IEEE division, three exact quotients
+#ifdef RT_ABL_FASTDIV
+#define RT_FDIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#else
+#define RT_FDIV(a, b) ((a) / (b))
+#endif
+                const float rn = RT_FDIV(1.0f, n); // one IEEE division, three exact quotients
                 float t  = div_by_recip(sx * gxn + sy * gyn + 1e-12f, n, rn);
                 float fx = div_by_recip(gxn, n, rn) - sx * t;
                 float fy = div_by_recip(gyn, n, rn) - sy * t;
                 float fz = -sz * t;
-                float h  = P.c_h1 / fabsf(t); // c * 0.1f / |t|
+                float h  = RT_FDIV(P.c_h1, fabsf(t)); // c * 0.1f / |t|
                 h        = h < dzcap ? h : dzcap;
-                float h2 = 1.0001f * (lim2 - fabsf(rz)) / fabsf(sz);
-                float h3 = P.c_h3 * (fabsf(sx) + 5e-4f) / (fabsf(fx) + 1e-8f); // c * 0.05f * ...
-                float h4 = P.c_h3 * (fabsf(sy) + 5e-4f) / (fabsf(fy) + 1e-8f);
+                float h2 = RT_FDIV(1.0001f * (lim2 - fabsf(rz)), fabsf(sz));
+                float h3 = RT_FDIV(P.c_h3 * (fabsf(sx) + 5e-4f), (fabsf(fx) + 1e-8f)); // c * 0.05f * ...
+                float h4 = RT_FDIV(P.c_h3 * (fabsf(sy) + 5e-4f), (fabsf(fy) + 1e-8f));
                 h        = h < h2 ? h : h2;
                 h        = h < h3 ? h : h3;
                 h        = h < h4 ? h : h4;
@@ -511,6 +527,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 }
             }
         }
+        } // some lane is marching
     }
 
     // ---- launch totals ----
@@ -523,6 +540,13 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             atomicAdd(&P.ctl->n_skipped, (unsigned long long) k);
             atomicAdd(&P.ctl->n_rays, (unsigned long long) r);
         }
+#ifdef RT_TIMEBLOCKS
+        if (lane == 0) {
+            for (int i = 0; i < 6; i++)
+                atomicAdd(&g_inst[i], tb_acc[i]);
+            atomicAdd(&g_inst[7], tb_iters);
+        }
+#endif
 #ifdef RT_INSTRUMENT
         for (int i = 0; i < 3; i++) {
             unsigned tw = wave_sum_u32(inst.w[i]), ta = wave_sum_u32(inst.a[i]);

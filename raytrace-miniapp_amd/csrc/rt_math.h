@@ -30,6 +30,21 @@ struct Inst {
 #else
 #define RT_TICK(i)
 #endif
+// Second diagnostic build (-DRT_TIMEBLOCKS): wave clock spent in each block of the march
+// loop, g_inst[i] = cycles between mark i and mark i+1 summed over waves, g_inst[7] = iterations.
+#ifdef RT_TIMEBLOCKS
+#ifndef RT_INSTRUMENT
+__device__ unsigned long long g_inst[8];
+#endif
+#define RT_MARK(i)                                                      \
+    {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        tb_acc[i] += now_ - tb_last;                                    \
+        tb_last = now_;                                                 \
+    }
+#else
+#define RT_MARK(i)
+#endif
 
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & (WAVE - 1)); }
@@ -59,7 +74,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 __device__ __forceinline__ void renormalise(float &sx, float &sy, float &sz)
 {
     float q   = sx * sx + sy * sy + sz * sz;
+#ifdef RT_ABL_FASTDIV
+    float inv = __builtin_amdgcn_rsqf(q);
+#else
     float inv = 1.0f / sqrtf(q);
+#endif
     sx *= inv;
     sy *= inv;
     sz *= inv;
@@ -78,10 +97,12 @@ __device__ __forceinline__ float div_by_recip(float a, float b, float y)
     const float r = fmaf(-b, q, a);
     float c       = fmaf(r, y, q);
     c             = (r == 0.0f) ? q : c;
+#ifndef RT_ABL_NOGUARD
     if (fabsf(a) < 1e-29f && a != 0.0f) { // the residual must stay a normal float: |a| > 2^-102 (CPU test: none above 3e-32)
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
         c = a / b;
     }
+#endif
     return c;
 }
 __device__ __forceinline__ double div_by_recip(double a, double b, double y)
@@ -90,10 +111,12 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double y)
     const double r = fma(-b, q, a);
     double c       = fma(r, y, q);
     c              = (r == 0.0) ? q : c;
+#ifndef RT_ABL_NOGUARD
     if (fabs(a) < 1e-280 && a != 0.0) { // residual normal: |a| > 2^-969
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
         c = a / b;
     }
+#endif
     return c;
 }
 
