@@ -1,7 +1,7 @@
 // rt_device.h -- device-side records of the HIP ray-trace backend (gfx950).
 //
 // Layout in HBM (one arena per plan, packed by rt_hip_plan_create):
-//   march blob (BlobGain below): per length ii = 1..N-1 (gain[0] is never read on the
+//   march blob (BlobGain, Interval below): per length ii = 1..N-1 (gain[0] is never read on the
 //     path except for the E0 != NULL test, src/common/RayTraceImageHelper.h:402,435-441)
 //     x[Nx], y[Ny] (f64), reciprocal pairs per grid interval, and
 //     node[Nx*Ny] = {double n; float g0; float E0}: the three quantities a cell-step
@@ -34,18 +34,29 @@ struct DevGain {
 
 // Header of one length inside the "march blob": everything the march gathers, laid
 // out so that a work-group can copy the whole blob into LDS verbatim.
-//   blob = BlobGain[N] | per length: x[Nx] (f64) | y[Ny] (f64) | rx[Nx] | ry[Ny] | Node[Nx*Ny]
-// rx[k] = {1/(x[k]-x[k-1]), 1/(double)(float)(x[k]-x[k-1])}: the correctly rounded
-// reciprocals of the two divisors a cell uses (Helper.h:482-483 and :323,330-334),
-// computed once on the host with IEEE division so that the kernel divides by
-// multiplication + exact residual correction (rt_math.h, div_by_recip).
+//   blob = BlobGain[N] | per length: Interval x[Nx] | Interval y[Ny] | Node[Nx*Ny]
 // off_* are byte offsets from the start of the blob (16-byte aligned).
 struct alignas(16) BlobGain {
     float lo_x, hi_x, lo_y, hi_y; // plasma box as floats (Helper.h:445-453), lo_y = -hi_y if mirrored
-    int Nx, Ny, mirror_y, off_x;
-    int off_y, off_node, off_rx, off_ry;
+    int Nx, Ny, mirror_y, off_ix;
+    int off_iy, off_node, pad0, pad1;
     double x0, y0;                // x[0], y[0]
     double inv_hx, inv_hy;        // (Nx-1)/(x[Nx-1]-x[0]): index guess on uniform grids
+};
+
+// One grid interval (g[u-1], g[u]] of one axis, u = 1 .. n-1 (entry 0 unused): everything a
+// cell setup derives from the two coordinates (Helper.h:465-497, :323-324), computed once on
+// the host with the same IEEE operations, so that the setup is one 48-byte gather per axis.
+// rh and rw are the correctly rounded reciprocals of the two divisors a cell uses
+// (Helper.h:482-483 and :330-334): the kernel divides by multiplication + exact residual
+// correction (rt_math.h, div_by_recip).
+struct alignas(16) Interval {
+    double lo, hi; // g[u-1], g[u]
+    double rh, rw; // RN(1 / (hi - lo)), RN(1 / (double) (float) (hi - lo))
+    float w;       // (float) (hi - lo)
+    float b_lo;    // (float) (lo - 0.1 (hi - lo)); mirrored y axis, u = 1: -b_hi (Helper.h:494-495)
+    float b_hi;    // (float) (hi + 0.1 (hi - lo))
+    float pad;
 };
 
 struct DevSeed {

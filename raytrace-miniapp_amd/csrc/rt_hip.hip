@@ -436,27 +436,28 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             h.inv_hx = 0.0;
         if (!std::isfinite(h.inv_hy))
             h.inv_hy = 0.0;
-        h.off_x    = (int) blob.size();
-        blob.resize(align_up(blob.size() + sizeof(double) * (size_t) g.Nx, 16));
-        memcpy(blob.data() + h.off_x, g.x, sizeof(double) * (size_t) g.Nx);
-        h.off_y = (int) blob.size();
-        blob.resize(align_up(blob.size() + sizeof(double) * (size_t) g.Ny, 16));
-        memcpy(blob.data() + h.off_y, g.y, sizeof(double) * (size_t) g.Ny);
-        // reciprocal pairs per grid interval (entry 0 unused)
-        auto put_recips = [&](const double *gp, int n) {
+        // per-interval records of both axes (entry 0 unused)
+        auto put_intervals = [&](const double *gp, int n, bool mirrored) {
             const int off = (int) blob.size();
-            blob.resize(blob.size() + 16 * (size_t) n);
-            double *r = reinterpret_cast<double *>(blob.data() + off);
-            r[0] = r[1] = 0.0;
+            blob.resize(blob.size() + sizeof(rt::Interval) * (size_t) n);
+            rt::Interval *iv = reinterpret_cast<rt::Interval *>(blob.data() + off);
+            memset(iv, 0, sizeof(rt::Interval) * (size_t) n);
             for (int k = 1; k < n; k++) {
-                const double hk = gp[k] - gp[k - 1];
-                r[2 * k]        = 1.0 / hk;
-                r[2 * k + 1]    = 1.0 / (double) (float) hk;
+                const double lo = gp[k - 1], hi = gp[k], hk = hi - lo;
+                iv[k].lo   = lo;
+                iv[k].hi   = hi;
+                iv[k].rh   = 1.0 / hk;
+                iv[k].rw   = 1.0 / (double) (float) hk;
+                iv[k].w    = (float) hk;
+                iv[k].b_lo = (float) (lo - 0.1 * hk);
+                iv[k].b_hi = (float) (hi + 0.1 * hk);
+                if (mirrored && k == 1)
+                    iv[k].b_lo = -iv[k].b_hi;
             }
             return off;
         };
-        h.off_rx   = put_recips(g.x, g.Nx);
-        h.off_ry   = put_recips(g.y, g.Ny);
+        h.off_ix   = put_intervals(g.x, g.Nx, false);
+        h.off_iy   = put_intervals(g.y, g.Ny, h.mirror_y != 0);
         h.off_node = (int) blob.size();
         blob.resize(blob.size() + sizeof(rt::Node) * npix);
         rt::Node *nd = reinterpret_cast<rt::Node *>(blob.data() + h.off_node);

@@ -27,11 +27,6 @@
 
 namespace rt {
 
-struct alignas(16) Recip2 {
-    double rh; // 1 / (g[k] - g[k-1])
-    double rw; // 1 / (double) (float) (g[k] - g[k-1])
-};
-
 enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 };
 
 // start ray of flat index ridx: position, and tangent of the launch angles
@@ -130,34 +125,29 @@ extern "C" __global__ void __launch_bounds__(256) rt_tan_kernel(const rt_ray *ra
     }
 }
 
-// Helper.h:131-143 on a blob grid.  The bisection returns the unique u in
-// [1, n-1] with (u == 1 || g[u-1] < v) && (u == n-1 || g[u] >= v) on a
-// non-decreasing grid: guess u arithmetically (exact on the uniform grids the
-// files hold), verify with the two coordinates the cell-step needs anyway, and
-// only bisect when the guess fails.  Returns u and g[u-1], g[u].
-__device__ __forceinline__ uint32_t find_interval(const double *g, int n, double g0, double inv_h, double v,
-                                                  double &c_lo, double &c_hi)
+// Helper.h:131-143 on the interval records of one axis: the unique u in [1, n-1] with
+// (u == 1 || g[u-1] < v) && (u == n-1 || g[u] >= v) on a non-decreasing grid.  The cell
+// setup guesses u arithmetically (exact on the uniform grids the files hold) and verifies
+// the guess with the two coordinates it gathers anyway; this bisection runs when the guess
+// fails (non-uniform grid, rounding at an interval edge).  g[mid] = iv[mid].hi for the
+// interior points the bisection probes.
+__device__ __forceinline__ int bisect_interval(const Interval *iv, int n, double v)
+{
+    int lo = 0, hi = n - 1;
+    while (hi - lo != 1) {
+        int mid = (hi + lo) / 2;
+        if (iv[mid].hi >= v)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    return hi;
+}
+__device__ __forceinline__ int guess_interval(int n, double g0, double inv_h, double v)
 {
     const int last = n - 1;
     int u          = (int) ((v - g0) * inv_h) + 1;
-    u              = u < 1 ? 1 : (u > last ? last : u);
-    c_lo           = g[u - 1];
-    c_hi           = g[u];
-    const bool ok  = (u == 1 || c_lo < v) && (u == last || c_hi >= v);
-    if (!ok) {
-        int lo = 0, hi = last;
-        while (hi - lo != 1) {
-            int mid = (hi + lo) / 2;
-            if (g[mid] >= v)
-                hi = mid;
-            else
-                lo = mid;
-        }
-        u    = hi;
-        c_lo = g[u - 1];
-        c_hi = g[u];
-    }
-    return (uint32_t) u;
+    return u < 1 ? 1 : (u > last ? last : u);
 }
 
 template <bool LDS_TAB>
@@ -360,40 +350,52 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 if ((px < G.lo_x) | (px > G.hi_x) | (py < G.lo_y) | (py > G.hi_y) | (sz * sz <= 0.01f)) {
                     escaped = true; // its slot is committed by [A1] next iteration
                 } else {
-                    mirror           = G.mirror_y != 0;
-                    const double *gx = reinterpret_cast<const double *>(tab + G.off_x);
-                    const double *gy = reinterpret_cast<const double *>(tab + G.off_y);
-                    const Node *node = reinterpret_cast<const Node *>(tab + G.off_node);
-                    const float ya   = mirror ? fabsf(py) : py;
-                    double xc1, yc1;
-                    const int k1 = (int) find_interval(gx, G.Nx, G.x0, G.inv_hx, (double) px, xc0, xc1);
-                    const int k2 = (int) find_interval(gy, G.Ny, G.y0, G.inv_hy, (double) ya, yc0, yc1);
-                    c00          = (k1 - 1) + (k2 - 1) * G.Nx;
-                    node_off     = G.off_node + c00 * (int) sizeof(Node);
-                    row_bytes    = G.Nx * (int) sizeof(Node);
-                    const Node a00 = node[c00], a10 = node[c00 + 1];
-                    const Node a01 = node[c00 + G.Nx], a11 = node[c00 + G.Nx + 1];
-                    const double hx = xc1 - xc0, hy = yc1 - yc0;
-                    const Recip2 qx = reinterpret_cast<const Recip2 *>(tab + G.off_rx)[k1];
-                    const Recip2 qy = reinterpret_cast<const Recip2 *>(tab + G.off_ry)[k2];
-                    rwx             = qx.rw;
-                    rwy             = qy.rw;
-                    const float u   = (float) div_by_recip((double) px - xc0, hx, qx.rh);
-                    const float v   = (float) div_by_recip((double) ya - yc0, hy, qy.rh);
-                    g0              = lerp2(u, v, a00.g0, a10.g0, a01.g0, a11.g0);
-                    E0              = 0.0f;
+                    mirror              = G.mirror_y != 0;
+                    const Interval *ivx = reinterpret_cast<const Interval *>(tab + G.off_ix);
+                    const Interval *ivy = reinterpret_cast<const Interval *>(tab + G.off_iy);
+                    const Node *node    = reinterpret_cast<const Node *>(tab + G.off_node);
+                    const float ya      = mirror ? fabsf(py) : py;
+                    const double pxd = (double) px, yad = (double) ya;
+                    // one round of gathers on the guessed cell: two interval records, four nodes
+                    int k1     = guess_interval(G.Nx, G.x0, G.inv_hx, pxd);
+                    int k2     = guess_interval(G.Ny, G.y0, G.inv_hy, yad);
+                    Interval X = ivx[k1], Y = ivy[k2];
+                    c00        = (k1 - 1) + (k2 - 1) * G.Nx;
+                    Node a00 = node[c00], a10 = node[c00 + 1];
+                    Node a01 = node[c00 + G.Nx], a11 = node[c00 + G.Nx + 1];
+                    const bool ok = ((k1 == 1) | (X.lo < pxd)) & ((k1 == G.Nx - 1) | (X.hi >= pxd)) &
+                                    ((k2 == 1) | (Y.lo < yad)) & ((k2 == G.Ny - 1) | (Y.hi >= yad));
+                    if (!ok) {
+                        k1  = bisect_interval(ivx, G.Nx, pxd);
+                        k2  = bisect_interval(ivy, G.Ny, yad);
+                        X   = ivx[k1];
+                        Y   = ivy[k2];
+                        c00 = (k1 - 1) + (k2 - 1) * G.Nx;
+                        a00 = node[c00];
+                        a10 = node[c00 + 1];
+                        a01 = node[c00 + G.Nx];
+                        a11 = node[c00 + G.Nx + 1];
+                    }
+                    node_off  = G.off_node + c00 * (int) sizeof(Node);
+                    row_bytes = G.Nx * (int) sizeof(Node);
+                    xc0       = X.lo;
+                    yc0       = Y.lo;
+                    rwx       = X.rw;
+                    rwy       = Y.rw;
+                    const float u = (float) div_by_recip(pxd - xc0, X.hi - X.lo, X.rh);
+                    const float v = (float) div_by_recip(yad - yc0, Y.hi - Y.lo, Y.rh);
+                    g0            = lerp2(u, v, a00.g0, a10.g0, a01.g0, a11.g0);
+                    E0            = 0.0f;
                     if (use_emis) {
                         E0 = lerp2(u, v, a00.E0, a10.E0, a01.E0, a11.E0);
                         E0 = E0 >= 0 ? E0 : 0.0f;
                     }
-                    wx = (float) hx; // Helper.h:323-324
-                    wy = (float) hy;
-                    b0 = (float) (xc0 - 0.1 * hx);
-                    b1 = (float) (xc1 + 0.1 * hx);
-                    b2 = (float) (yc0 - 0.1 * hy);
-                    b3 = (float) (yc1 + 0.1 * hy);
-                    if (mirror && k2 <= 1)
-                        b2 = -b3;
+                    wx = X.w; // Helper.h:323-324
+                    wy = Y.w;
+                    b0 = X.b_lo;
+                    b1 = X.b_hi;
+                    b2 = Y.b_lo;
+                    b3 = Y.b_hi;
                     pz    = 0.0f;
                     zc    = 0.0f;
                     path  = 0.0f;
