@@ -412,6 +412,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     // march blob: headers + grids + fused corner nodes of every length, copied to LDS
     // verbatim by rt_march_kernel<true>
     std::vector<unsigned char> blob(align_up(sizeof(rt::BlobGain) * (size_t) N, 16));
+    bool tiny_spacing = false;
     for (int i = 1; i < N; i++) {
         const rt_gain &g  = gain[i];
         const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
@@ -444,6 +445,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             memset(iv, 0, sizeof(rt::Interval) * (size_t) n);
             for (int k = 1; k < n; k++) {
                 const double lo = gp[k - 1], hi = gp[k], hk = hi - lo;
+                if (hk > 0.0 && hk < 1e-200)
+                    tiny_spacing = true; // see rt_math.h, div_by_recip<TINY_OK>
                 iv[k].lo   = lo;
                 iv[k].hi   = hi;
                 iv[k].rh   = 1.0 / hk;
@@ -467,6 +470,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             nd[c].E0 = g.E0 ? g.E0[c] : 0.0f;
         }
         memcpy(blob.data() + sizeof(rt::BlobGain) * (size_t) i, &h, sizeof(h));
+    }
+    if (tiny_spacing) {
+        delete p;
+        return fail_arg("rt_hip_plan_create: gain grid spacing below 1e-200");
     }
     const size_t off_blob = ab.put(blob.data(), blob.size());
 

@@ -382,8 +382,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     yc0       = Y.lo;
                     rwx       = X.rw;
                     rwy       = Y.rw;
-                    const float u = (float) div_by_recip(pxd - xc0, X.hi - X.lo, X.rh);
-                    const float v = (float) div_by_recip(yad - yc0, Y.hi - Y.lo, Y.rh);
+                    const float u = (float) div_by_recip<true>(pxd - xc0, X.hi - X.lo, X.rh);
+                    const float v = (float) div_by_recip<true>(yad - yc0, Y.hi - Y.lo, Y.rh);
                     g0            = lerp2(u, v, a00.g0, a10.g0, a01.g0, a11.g0);
                     E0            = 0.0f;
                     if (use_emis) {
@@ -446,13 +446,13 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             const double n11 = *reinterpret_cast<const double *>(tab + node_off + row_bytes + (int) sizeof(Node));
             const float ya   = mirror ? fabsf(py) : py;
             const double dwx = (double) wx, dwy = (double) wy;
-            const float u    = (float) div_by_recip((double) px - xc0, dwx, rwx);
-            const float v    = (float) div_by_recip((double) ya - yc0, dwy, rwy);
+            const float u    = (float) div_by_recip<true>((double) px - xc0, dwx, rwx);
+            const float v    = (float) div_by_recip<true>((double) ya - yc0, dwy, rwy);
             n0  = lerp2(u, v, (float) n00, (float) n10, (float) n01, (float) n11);
-            gxn = (float) (div_by_recip((1.0 - (double) v) * (n10 - n00), dwx, rwx) +
-                           div_by_recip((double) v * (n11 - n01), dwx, rwx));
-            gyn = (float) (div_by_recip((1.0 - (double) u) * (n01 - n00), dwy, rwy) +
-                           div_by_recip((double) u * (n11 - n10), dwy, rwy));
+            gxn = (float) (div_by_recip<true>((1.0 - (double) v) * (n10 - n00), dwx, rwx) +
+                           div_by_recip<true>((double) v * (n11 - n01), dwx, rwx));
+            gyn = (float) (div_by_recip<true>((1.0 - (double) u) * (n01 - n00), dwy, rwy) +
+                           div_by_recip<true>((double) u * (n11 - n10), dwy, rwy));
             if (mirror && py < 0)
                 gyn = -gyn;
             lim2  = dzrem - zc;
@@ -494,11 +494,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 h        = h < h4 ? h : h4;
                 float ht = h * t;
                 const float R3 = 1.0f / 3.0f, R6 = 1.0f / 6.0f, R12 = 1.0f / 12.0f; // RN(1/b), folded
-                float c1 = 0.5f * h * h * (1.0f - div_by_recip(ht, 3.0f, R3) + div_by_recip(ht * ht, 12.0f, R12));
+                float c1 = 0.5f * h * h * (1.0f - div_by_recip<true>(ht, 3.0f, R3) + div_by_recip<true>(ht * ht, 12.0f, R12));
                 rx += sx * h + c1 * fx;
                 ry += sy * h + c1 * fy;
                 rz += sz * h + c1 * fz;
-                float c2 = h * (1.0f - 0.5f * ht + div_by_recip(ht * ht, 6.0f, R6));
+                float c2 = h * (1.0f - 0.5f * ht + div_by_recip<true>(ht * ht, 6.0f, R6));
                 sx += c2 * fx;
                 sy += c2 * fy;
                 sz += c2 * fz;

@@ -88,31 +88,39 @@ __device__ __forceinline__ void renormalise(float &sx, float &sy, float &sz)
 // q = RN(a*y), r = a - b*q (exact with FMA), result RN(q + r*y) = RN(a/b)
 // (Markstein's correction step).  Checked against IEEE division on the CPU by
 // tests/test_float_identities.py (1e9 random pairs, and every float for the
-// constant divisors); two cases are routed away from the correction because it
+// constant divisors).  Two cases are routed away from the correction because it
 // is not exact there: a zero residual keeps q (preserves the sign of a zero
-// quotient), and quotients in or near the subnormal range take a true division.
-__device__ __forceinline__ float div_by_recip(float a, float b, float y)
+// quotient), and dividends so small that the residual leaves the normal range
+// (|a| < 1e-29f, resp. 1e-280) take a true division -- unless the caller states
+// that such a quotient cannot matter (TINY_OK):
+//   * float, TINY_OK: the quotient is added to 1.0f (ht/3, ht^2/12, ht^2/6 in the
+//     integrator step): below 2^-26 it is absorbed whatever its last bits are;
+//   * double, TINY_OK: the quotient (or its sum with another such quotient) is narrowed
+//     to float: with divisors above 1e-200 (plan_create checks the grid spacings) a
+//     quotient of a dividend below 1e-280 lies below 1e-80 and narrows to a zero of
+//     the right sign either way.
+template <bool TINY_OK = false> __device__ __forceinline__ float div_by_recip(float a, float b, float y)
 {
     const float q = a * y;
     const float r = fmaf(-b, q, a);
     float c       = fmaf(r, y, q);
     c             = (r == 0.0f) ? q : c;
 #ifndef RT_ABL_NOGUARD
-    if (fabsf(a) < 1e-29f && a != 0.0f) { // the residual must stay a normal float: |a| > 2^-102 (CPU test: none above 3e-32)
+    if (!TINY_OK && fabsf(a) < 1e-29f && a != 0.0f) { // the residual must stay a normal float: |a| > 2^-102 (CPU test: none above 3e-32)
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
         c = a / b;
     }
 #endif
     return c;
 }
-__device__ __forceinline__ double div_by_recip(double a, double b, double y)
+template <bool TINY_OK = false> __device__ __forceinline__ double div_by_recip(double a, double b, double y)
 {
     const double q = a * y;
     const double r = fma(-b, q, a);
     double c       = fma(r, y, q);
     c              = (r == 0.0) ? q : c;
 #ifndef RT_ABL_NOGUARD
-    if (fabs(a) < 1e-280 && a != 0.0) { // residual normal: |a| > 2^-969
+    if (!TINY_OK && fabs(a) < 1e-280 && a != 0.0) { // residual normal: |a| > 2^-969
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
         c = a / b;
     }
