@@ -79,6 +79,12 @@ struct DevRays {
     const float *sxy;   // list mode: {tan(1e-3 a), tan(1e-3 b)} per ray (rt_tan_kernel)
     const double *gx, *gy, *ga, *gb;
     const float *tan_a, *tan_b; // grid mode: tanf(1e-3f * (float) ga[k]), host-computed
+    // grid mode, forward method with a seed: the seed profile is a product of one factor per
+    // grid axis (Helper.h:230-244), tabulated per grid point by rt_seed_tab_kernel with the very
+    // routine the per-ray path uses: sf = [ngx | ngy | nga | ngb] factors, sin = inside the
+    // profile's support (1) or not (0).  NULL: evaluate per ray.
+    const double *sf;
+    const unsigned char *sin;
     int ngx, ngy, nga, ngb;
     long long first, stride;
     unsigned long long count;

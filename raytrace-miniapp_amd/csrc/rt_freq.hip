@@ -216,10 +216,20 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             r2.b = atanf_flt32_kernel(m.sy / m.sz) * 1e3f;
         }
         if (P.has_seed && !(fl & F_ESCAPED)) { // Helper.h:523-533
-            if (P.method == 1)
+            if (P.method == 1) {
                 f0 = seed_factor(P.seed, (double) m.px, (double) m.py, (double) r2.a, (double) r2.b);
-            else
+            } else if (P.rays.sf) {
+                // the launch ray is a grid point: product of the tabulated factors, in seed_factor's order
+                unsigned gi, gj, gk, gm;
+                grid_index(P.rays, ridx, gi, gj, gk, gm);
+                const unsigned oj = (unsigned) P.rays.ngx, ok = oj + (unsigned) P.rays.ngy, om = ok + (unsigned) P.rays.nga;
+                if (P.rays.sin[gi] & P.rays.sin[oj + gj] & P.rays.sin[ok + gk] & P.rays.sin[om + gm]) {
+                    f0 = P.seed.f0 * P.rays.sf[gi] * P.rays.sf[oj + gj] * P.rays.sf[ok + gk] * P.rays.sf[om + gm];
+                    f0 = f0 < 0.0 ? 0.0 : f0;
+                }
+            } else {
                 f0 = seed_factor(P.seed, (double) ray.x, (double) ray.y, (double) ray.a, (double) ray.b);
+            }
         }
         if (P.method != 1) { // RayTraceImageCPU.cpp:37-49
             out   = r2;
@@ -490,12 +500,20 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             }
         });
     } else if (cached) {
-        double *my_row = cache + (size_t) run_id * (size_t) K;
+        // LDS atomics serialise on equal addresses (the lanes of one run): quads that lie inside
+        // one run add their four values with two quad_perm DPP steps and send one atomic
+        double *my_row      = cache + (size_t) run_id * (size_t) K;
+        const int rid_first = __builtin_amdgcn_update_dpp(0, run_id, 0x00, 0xf, 0xf, true); // quad_perm:[0,0,0,0]
+        const int rid_last  = __builtin_amdgcn_update_dpp(0, run_id, 0xff, 0xf, 0xf, true); // quad_perm:[3,3,3,3]
+        const bool quad_one = rid_first == rid_last; // run ids do not decrease along the lanes
+        const bool sender   = pix >= 0 && (!quad_one || (lane & 3) == 0);
         frequency_loop([&](int kb, double (&v)[VEC]) {
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-                if (pix >= 0)
-                    unsafeAtomicAdd(&my_row[kb + j], v[j]);
+                double q4 = dpp_step<0xb1, 0xf>(v[j]); // quad_perm:[1,0,3,2]
+                q4        = dpp_step<0x4e, 0xf>(q4);   // quad_perm:[2,3,0,1]
+                if (sender)
+                    unsafeAtomicAdd(&my_row[kb + j], quad_one ? q4 : v[j]);
             }
         });
     } else {

@@ -153,6 +153,7 @@ struct rt_hip_plan {
     rt_ray *rays_dev   = nullptr;
     double *grid_dev   = nullptr; // ray grids when rays are generated
     float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
+    double *seedtab_dev = nullptr; // grid mode with a seed: per-axis seed factors + support flags
     std::vector<double> beam_x, beam_y, beam_a, beam_b; // host copies, to recognise ray grid == beam grid
     unsigned char *rec = nullptr; // per-ray march records (two-kernel path)
     bool path_on       = false;   // path tracer instead of the image (rt_hip_plan_enable_path)
@@ -189,14 +190,16 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
     const int in_lds       = ang_bytes <= 32 * 1024;
-    // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K
-    // doubles in at most 5 KB per wave -- with the static scratch (transposition rows, exp
-    // table) and the I_ang histogram that leaves room for the four work-groups per CU the
-    // register budget allows; fewer than 4 rows is not worth having
-    int nslot = (int) ((5 * 1024) / ((size_t) p->P.K * sizeof(double)));
-    nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
-    const size_t lds      = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
+    // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K doubles,
+    // sized so that the RT_FREQ_WAVES work-groups per CU the register budget allows still fit
+    // into LDS beside the static scratch (transposition rows, exp table) and the I_ang
+    // histogram; fewer than 4 rows is not worth having
     const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + 64 * sizeof(double);
+    const size_t lds_fix  = lds_stat + (in_lds ? ang_bytes : 0) + 1024;
+    const size_t lds_wg   = (size_t) (160 * 1024) / RT_FREQ_WAVES;
+    int nslot = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / ((size_t) 4 * (size_t) p->P.K * sizeof(double))) : 0;
+    nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
+    const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
     // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
     // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
     // (surplus work-groups find the tile counter exhausted and leave)
@@ -331,6 +334,7 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
     (void) hipFree(p->arena);
     pool_free(p->device, p->rays_dev);
     (void) hipFree(p->grid_dev);
+    (void) hipFree(p->seedtab_dev);
     (void) hipFree(p->image_own);
     (void) hipFree(p->iang_own);
     (void) hipFree(p->ctl);
@@ -611,6 +615,8 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     HIP_TRY(hipSetDevice(p->device));
     (void) hipFree(p->grid_dev);
     p->grid_dev     = nullptr;
+    (void) hipFree(p->seedtab_dev);
+    p->seedtab_dev  = nullptr;
     const size_t nn = (size_t) ngx + (size_t) ngy + (size_t) nga + (size_t) ngb;
     std::vector<double> h(nn);
     memcpy(h.data(), gx, sizeof(double) * (size_t) ngx);
@@ -647,6 +653,16 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     R.stride       = stride;
     R.count        = (unsigned long long) count;
     p->n_rays      = (unsigned long long) count;
+    if (p->P.has_seed && p->P.method != 1) {
+        HIP_TRY(hipMalloc((void **) &p->seedtab_dev, nn * sizeof(double) + nn));
+        unsigned char *flags = reinterpret_cast<unsigned char *>(p->seedtab_dev + nn);
+        hipLaunchKernelGGL(rt::rt_seed_tab_kernel, dim3((unsigned) ((nn + 255) / 256)), dim3(256), 0, nullptr, p->P.seed,
+                           R, p->seedtab_dev, flags);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        R.sf  = p->seedtab_dev;
+        R.sin = flags;
+    }
     // One ray per pixel, every pixel covered: in ASE mode ray ijkm lands in pixel (i, j)
     // (SURVEY.md 8(c) i) -- the deposit index of the ray is verified per ray by the kernel,
     // which falls back to atomics for any ray that does not land in its own pixel.

@@ -29,6 +29,20 @@ namespace rt {
 
 enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 };
 
+// grid mode: indices of ray ridx on the four ray grids
+// (RayTraceImage.cpp:300-328: b fastest, then a, y, x)
+__device__ __forceinline__ void grid_index(const DevRays &R, unsigned ridx, unsigned &i, unsigned &j, unsigned &k,
+                                           unsigned &m)
+{
+    unsigned ijkm = (unsigned) (R.first + (long long) ridx * R.stride);
+    m             = ijkm % (unsigned) R.ngb;
+    unsigned q    = ijkm / (unsigned) R.ngb;
+    k             = q % (unsigned) R.nga;
+    q /= (unsigned) R.nga;
+    j = q % (unsigned) R.ngy;
+    i = q / (unsigned) R.ngy;
+}
+
 // start ray of flat index ridx: position, and tangent of the launch angles
 __device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray &ray, float &ta, float &tb,
                                          bool want_tan)
@@ -40,14 +54,8 @@ __device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray
             tb = R.sxy[2 * (size_t) ridx + 1];
         }
     } else {
-        // RayTraceImage.cpp:300-328: b fastest, then a, y, x; grids rounded to float
-        unsigned ijkm = (unsigned) (R.first + (long long) ridx * R.stride);
-        unsigned m    = ijkm % (unsigned) R.ngb;
-        unsigned q    = ijkm / (unsigned) R.ngb;
-        unsigned k    = q % (unsigned) R.nga;
-        q /= (unsigned) R.nga;
-        unsigned j = q % (unsigned) R.ngy;
-        unsigned i = q / (unsigned) R.ngy;
+        unsigned i, j, k, m;
+        grid_index(R, ridx, i, j, k, m);
         ray.x      = (float) R.gx[i];
         ray.y      = (float) R.gy[j];
         ray.a      = (float) R.ga[k];
@@ -111,6 +119,23 @@ __device__ __forceinline__ float atanf_flt32_kernel(float x)
     const float s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
     const float s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
     return x - x * (s1 + s2);
+}
+
+// grid mode with a seed, forward method: the per-axis factors of the seed profile at every
+// point of the four ray grids (the grid value rounded to float, as the ray carries it)
+extern "C" __global__ void __launch_bounds__(256) rt_seed_tab_kernel(const DevSeed sd, const DevRays R, double *sf,
+                                                                     unsigned char *sin)
+{
+    const int n0 = R.ngx, n1 = R.ngy, n2 = R.nga, n3 = R.ngb;
+    for (int t = (int) (blockIdx.x * blockDim.x + threadIdx.x); t < n0 + n1 + n2 + n3; t += (int) (gridDim.x * blockDim.x)) {
+        int d           = t < n0 ? 0 : (t < n0 + n1 ? 1 : (t < n0 + n1 + n2 ? 2 : 3));
+        const int i     = t - (d > 0 ? n0 : 0) - (d > 1 ? n1 : 0) - (d > 2 ? n2 : 0);
+        const double *g = d == 0 ? R.gx : (d == 1 ? R.gy : (d == 2 ? R.ga : R.gb));
+        const double v  = (double) (float) g[i];
+        const bool in   = v >= sd.x[d][0] && v <= sd.x[d][sd.dim[d] - 1]; // Helper.h:233-236
+        sin[t]          = in ? 1 : 0;
+        sf[t]           = in ? pchip_eval(sd.dim[d], sd.x[d], sd.f[d], v) : 0.0;
+    }
 }
 
 // list mode: tangents of the launch angles (Helper.h:409-410) for every ray, at full lane
