@@ -29,7 +29,7 @@ struct alignas(16) Node {
 // Per-length table that stays in HBM/L2: the lineshape rows read by the frequency kernel.
 // (Everything the march reads lives in the march blob below.)
 struct DevGain {
-    const float *gv; // [Nx*Ny][K], k fastest
+    const float *gv; // [Nx*Ny][Kp], k fastest, columns K..Kp-1 zero
 };
 
 // Header of one length inside the "march blob": everything the march gathers, laid
@@ -126,6 +126,10 @@ struct DevParams {
     int use_emis, has_seed;
     float dz0;
     int probe_on;
+    // Kp = K rounded up to a multiple of 4: row stride of the lineshape tables and length of
+    // the two per-frequency vectors (beam.dv, seed.f[4]) on the device, zero padded, so that the
+    // frequency kernel always takes four frequencies per pass
+    int Kp, pad_kp;
     double scale;
     DevBeam beam;
     DevSeed seed;

@@ -186,6 +186,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     double *win = xpose + 4 * XP_ROW; // [MAXQ][64] totals of the current window of 64 frequencies
     const int S           = SF ? SF : P.L * RT_N_SUB;
     const int K           = P.K;
+    const int Kp          = P.Kp; // row stride of the lineshape tables and of the row cache
     const unsigned n_rays = (unsigned) P.rays.count;
     const unsigned ridx   = tile * WAVE + (unsigned) lane;
     const bool have       = ridx < n_rays;
@@ -332,7 +333,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #ifdef RT_ABL_NOLOAD
                         const float *row = P.gain[s / RT_N_SUB + 1].gv + kb;
 #else
-                        const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) K + kb;
+                        const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) Kp + kb;
 #endif
                         w[s] = *reinterpret_cast<const FVec<VEC> *>(row);
                     }
@@ -357,7 +358,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         const float g1 = reinterpret_cast<const float *>(rec)[s];
                         const float e1 = reinterpret_cast<const float *>(rec)[S + s];
                         const int c1   = reinterpret_cast<const int *>(rec)[2 * S + s];
-                        const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
+                        const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
                         const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
@@ -385,7 +386,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                 for (int s = 0; s < S; s++) {
                     const float g1    = SF ? gs[SF ? s : 0] : reinterpret_cast<const float *>(rec)[s];
                     const int c1      = SF ? cs[SF ? s : 0] : reinterpret_cast<const int *>(rec)[2 * S + s];
-                    const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) K + kb;
+                    const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
                     const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
 #pragma unroll
                     for (int j = 0; j < VEC; j++)
@@ -401,7 +402,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             }
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-                const double iv = live ? Iv[j] : 0.0;
+                const double iv = (live && kb + j < K) ? Iv[j] : 0.0; // columns K .. Kp-1 are padding
                 bad_neg         = bad_neg || iv < 0.0; // Helper.h:582-594
                 bad_nan         = bad_nan || iv != iv;
                 angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
@@ -423,9 +424,9 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         frequency_loop([&](int kb, double (&v)[VEC]) {
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-                if (own_pix >= 0)
+                if (own_pix >= 0 && kb + j < K)
                     P.image[(size_t) own_pix * (size_t) K + (size_t) (kb + j)] = (pix == own_pix) ? v[j] : 0.0;
-                if (pix >= 0 && pix != own_pix)
+                if (pix >= 0 && pix != own_pix && kb + j < K)
                     unsafeAtomicAdd(&img_row[kb + j], v[j]);
             }
         });
@@ -502,7 +503,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     } else if (cached) {
         // LDS atomics serialise on equal addresses (the lanes of one run): quads that lie inside
         // one run add their four values with two quad_perm DPP steps and send one atomic
-        double *my_row      = cache + (size_t) run_id * (size_t) K;
+        double *my_row      = cache + (size_t) run_id * (size_t) Kp;
         const int rid_first = __builtin_amdgcn_update_dpp(0, run_id, 0x00, 0xf, 0xf, true); // quad_perm:[0,0,0,0]
         const int rid_last  = __builtin_amdgcn_update_dpp(0, run_id, 0xff, 0xf, 0xf, true); // quad_perm:[3,3,3,3]
         const bool quad_one = rid_first == rid_last; // run ids do not decrease along the lanes
@@ -539,7 +540,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     if ((lane - (1 << i)) >= run_start)
                         a += t;
                 }
-                if (tail)
+                if (tail && kb + j < K)
                     unsafeAtomicAdd(&img_row[kb + j], a);
             }
         });
@@ -554,8 +555,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             if (pq < 0)
                 continue;
             for (int k = lane; k < K; k += WAVE) {
-                const double v = cache[q * K + k];
-                cache[q * K + k] = 0.0;
+                const double v = cache[q * Kp + k];
+                cache[q * Kp + k] = 0.0;
                 unsafeAtomicAdd(&P.image[(size_t) pq * (size_t) K + (size_t) k], v);
             }
         }
@@ -584,8 +585,8 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
     double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
     const int n_ang  = P.beam.na * P.beam.nb;
     double *cache_wg = reinterpret_cast<double *>(lds_raw) + (iang_in_lds ? n_ang : 0);
-    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (size_t) nslot * (size_t) P.K;
-    for (int c = (int) threadIdx.x; c < 4 * nslot * P.K; c += (int) blockDim.x)
+    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (size_t) nslot * (size_t) P.Kp;
+    for (int c = (int) threadIdx.x; c < 4 * nslot * P.Kp; c += (int) blockDim.x)
         cache_wg[c] = 0.0;
     if (threadIdx.x < 64)
         exp2_tab[threadIdx.x] = exp2((double) threadIdx.x * (1.0 / 64.0));

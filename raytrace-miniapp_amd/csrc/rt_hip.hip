@@ -181,10 +181,6 @@ struct rt_hip_plan {
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
 // the shipped inputs; 0 = any N), VEC = frequencies per lane per pass
-#ifndef RT_ABL_VEC2
-#define RT_ABL_VEC2 0 // profiling only: 2 frequencies per pass where 4 would do
-#endif
-
 template <int SF, int VEC>
 static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
@@ -197,9 +193,9 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + 64 * sizeof(double);
     const size_t lds_fix  = lds_stat + (in_lds ? ang_bytes : 0) + 1024;
     const size_t lds_wg   = (size_t) (160 * 1024) / RT_FREQ_WAVES;
-    int nslot = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / ((size_t) 4 * (size_t) p->P.K * sizeof(double))) : 0;
+    int nslot = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / ((size_t) 4 * (size_t) p->P.Kp * sizeof(double))) : 0;
     nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
-    const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.K * sizeof(double);
+    const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.Kp * sizeof(double);
     // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
     // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
     // (surplus work-groups find the tile counter exhausted and leave)
@@ -288,15 +284,9 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
             HIP_TRY(hipGetLastError());
         }
     } else if (!(p->P.debug & 1u)) {
-        const int S = p->P.L * RT_N_SUB, K = p->P.K;
+        const int S = p->P.L * RT_N_SUB;
         int rc;
-        if (S == 6) {
-            rc = (K % 4 == 0 && !RT_ABL_VEC2) ? launch_freq<6, 4>(p, stream, 0)
-                              : (K % 2 == 0 ? launch_freq<6, 2>(p, stream, 0) : launch_freq<6, 1>(p, stream, 0));
-        } else {
-            rc = (K % 4 == 0) ? launch_freq<0, 4>(p, stream, 0)
-                              : (K % 2 == 0 ? launch_freq<0, 2>(p, stream, 0) : launch_freq<0, 1>(p, stream, 0));
-        }
+        rc = (S == 6) ? launch_freq<6, 4>(p, stream, 0) : launch_freq<0, 4>(p, stream, 0);
         if (rc != RT_OK)
             return rc;
     }
@@ -390,13 +380,24 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     std::vector<rt::DevGain> dg((size_t) N);
     std::vector<size_t> off_gv((size_t) N, 0);
     const bool use_emis = gain[0].E0 != nullptr && seed == nullptr; // Helper.h:402
-    for (int i = 1; i < N; i++)
-        off_gv[(size_t) i] = ab.put(gain[i].gv, sizeof(float) * (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K);
+    const int Kp = (K + 3) & ~3; // rows padded to four frequencies (DevParams::Kp)
+    for (int i = 1; i < N; i++) {
+        const size_t cells = (size_t) gain[i].Nx * (size_t) gain[i].Ny;
+        if (Kp == K) {
+            off_gv[(size_t) i] = ab.put(gain[i].gv, sizeof(float) * cells * (size_t) K);
+        } else {
+            off_gv[(size_t) i] = ab.reserve(sizeof(float) * cells * (size_t) Kp); // resize() zero-fills
+            float *dst         = reinterpret_cast<float *>(ab.host.data() + off_gv[(size_t) i]);
+            for (size_t c = 0; c < cells; c++)
+                memcpy(dst + c * (size_t) Kp, gain[i].gv + c * (size_t) K, sizeof(float) * (size_t) K);
+        }
+    }
     const size_t off_bx  = ab.put(beam->x, sizeof(double) * (size_t) beam->nx);
     const size_t off_by  = ab.put(beam->y, sizeof(double) * (size_t) beam->ny);
     const size_t off_ba  = ab.put(beam->a, sizeof(double) * (size_t) beam->na);
     const size_t off_bb  = ab.put(beam->b, sizeof(double) * (size_t) beam->nb);
-    const size_t off_bdv = ab.put(beam->dv, sizeof(double) * (size_t) beam->nv);
+    const size_t off_bdv = ab.reserve(sizeof(double) * (size_t) Kp);
+    memcpy(ab.host.data() + off_bdv, beam->dv, sizeof(double) * (size_t) beam->nv);
     size_t off_sx[5] = { 0 }, off_sf[5] = { 0 };
     if (seed) {
         for (int i = 0; i < 5; i++) {
@@ -404,12 +405,17 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
                 delete p;
                 return fail_arg("rt_hip_plan_create: incomplete seed table");
             }
+            if (i == 4 && seed->dim[4] != K) {
+                delete p;
+                return fail_arg("rt_hip_plan_create: seed.dim[4] != beam.nv");
+            }
             off_sx[i] = ab.put(seed->x[i], sizeof(double) * (size_t) seed->dim[i]);
-            off_sf[i] = ab.put(seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
-        }
-        if (seed->dim[4] != K) {
-            delete p;
-            return fail_arg("rt_hip_plan_create: seed.dim[4] != beam.nv");
+            if (i == 4) { // the frequency profile, padded like the lineshape rows
+                off_sf[i] = ab.reserve(sizeof(double) * (size_t) Kp);
+                memcpy(ab.host.data() + off_sf[i], seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
+            } else {
+                off_sf[i] = ab.put(seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
+            }
         }
     }
     const size_t off_gain = ab.reserve(sizeof(rt::DevGain) * (size_t) N);
@@ -503,6 +509,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     P.N        = N;
     P.L        = L;
     P.K        = K;
+    P.Kp       = Kp;
     P.method   = method;
     P.use_emis = use_emis ? 1 : 0;
     P.has_seed = seed ? 1 : 0;

@@ -48,7 +48,7 @@ extern "C" __global__ void __launch_bounds__(256) rt_path_kernel(const DevParams
             const float gs  = reinterpret_cast<const float *>(rec)[s];
             const float es  = reinterpret_cast<const float *>(rec)[S + s];
             const int cell  = reinterpret_cast<const int *>(rec)[2 * S + s];
-            const float w   = P.gain[s / RT_N_SUB + 1].gv[(size_t) cell * (size_t) K + (size_t) k];
+            const float w   = P.gain[s / RT_N_SUB + 1].gv[(size_t) cell * (size_t) P.Kp + (size_t) k];
             const double gl = (double) (gs * w);
             const double el = (double) (es * w);
             if (fabs(gl) < 1e-3) {
