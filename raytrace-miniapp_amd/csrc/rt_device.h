@@ -90,12 +90,15 @@ struct DevRays {
     unsigned long long count;
 };
 
-// Per-ray march record, one per ray at rec + ridx * rec_stride (AoS so that a
-// lane that finishes its ray writes one contiguous line):
-//   float gvl[S]; float evl[S]; int ivl[S];          S = (N-1)*3, Helper.h:386-388
-//   float px, py, sx, sy, sz;                        exit position / direction
-//   uint  flags | steps << 8;
+// Per-ray march record, one per ray at rec + ridx * rec_stride:
+//   RecSlot slot[S];    {gvl, evl, ivl} of each sub-segment, S = (N-1)*3, Helper.h:386-388
+//                       (one 12-byte store when a sub-segment ends)
+//   RecMeta meta;       exit position / direction, flags | steps << 8
 // rec_stride = round16(12 S + 24).
+struct RecSlot {
+    float g, e; // sum of g0 * path, E0 * path over the cells of the sub-segment
+    int c;      // index of its last cell
+};
 struct RecMeta {
     float px, py, sx, sy, sz;
     unsigned flags_steps;

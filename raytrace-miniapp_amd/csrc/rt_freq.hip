@@ -300,9 +300,10 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     if (SF) {
 #pragma unroll
         for (int s = 0; s < SF; s++) {
-            gs[s]          = reinterpret_cast<const float *>(rec)[s];
-            const float e1 = reinterpret_cast<const float *>(rec)[SF + s];
-            cs[s]          = reinterpret_cast<const int *>(rec)[2 * SF + s];
+            const RecSlot sl = reinterpret_cast<const RecSlot *>(rec)[s];
+            gs[s]            = sl.g;
+            const float e1   = sl.e;
+            cs[s]            = sl.c;
             rs[s]          = fabsf(gs[s]) >= RT_RS_MIN ? div_fast((double) e1, (double) gs[s]) : 0.0;
             if (use_emis && fabsf(gs[s]) >= RT_RS_MIN)
                 gs[s] = __builtin_amdgcn_fmed3f(gs[s], -P.gs_cap, P.gs_cap); // keeps |gs * gv| <= 708
@@ -345,7 +346,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         if (fabsf(gs[s]) >= RT_RS_MIN) {
                             ase_step<VEC>(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
-                            const float e1 = reinterpret_cast<const float *>(rec)[SF + s];
+                            const float e1 = reinterpret_cast<const RecSlot *>(rec)[s].e;
                             if (gs[s] != 0.0f || e1 != 0.0f) { // else the update is the identity
 #pragma unroll
                                 for (int j = 0; j < VEC; j++)
@@ -355,9 +356,9 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     }
                 } else {
                     for (int s = 0; s < S; s++) {
-                        const float g1 = reinterpret_cast<const float *>(rec)[s];
-                        const float e1 = reinterpret_cast<const float *>(rec)[S + s];
-                        const int c1   = reinterpret_cast<const int *>(rec)[2 * S + s];
+                        const RecSlot sl = reinterpret_cast<const RecSlot *>(rec)[s];
+                        const float g1 = sl.g, e1 = sl.e;
+                        const int c1   = sl.c;
                         const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
                         const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
 #pragma unroll
@@ -384,8 +385,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     gl[j] = 0.0;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    const float g1    = SF ? gs[SF ? s : 0] : reinterpret_cast<const float *>(rec)[s];
-                    const int c1      = SF ? cs[SF ? s : 0] : reinterpret_cast<const int *>(rec)[2 * S + s];
+                    const float g1    = SF ? gs[SF ? s : 0] : reinterpret_cast<const RecSlot *>(rec)[s].g;
+                    const int c1      = SF ? cs[SF ? s : 0] : reinterpret_cast<const RecSlot *>(rec)[s].c;
                     const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
                     const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
 #pragma unroll

@@ -912,12 +912,15 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
             HIP_TRY(hipMemcpy(h.data(), p->rec, h.size(), hipMemcpyDeviceToHost));
         for (size_t r = 0; r < n; r++) {
             const unsigned char *rec = h.data() + r * p->P.rec_stride;
-            if (gvl)
-                memcpy(gvl + r * S, rec, S * 4);
-            if (evl)
-                memcpy(evl + r * S, rec + S * 4, S * 4);
-            if (ivl)
-                memcpy(ivl + r * S, rec + S * 8, S * 4);
+            const rt::RecSlot *sl = reinterpret_cast<const rt::RecSlot *>(rec);
+            for (size_t q = 0; q < S; q++) {
+                if (gvl)
+                    gvl[r * S + q] = sl[q].g;
+                if (evl)
+                    evl[r * S + q] = sl[q].e;
+                if (ivl)
+                    ivl[r * S + q] = sl[q].c;
+            }
         }
     }
     if (ray2)

@@ -324,9 +324,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 const int is   = backward ? RT_N_SUB - iz - 1 : iz;
                 const int slot = (ii - 1) * RT_N_SUB + is;
 #ifndef RT_ABL_NOSTORE
-                reinterpret_cast<float *>(rec)[slot]       = gacc;
-                reinterpret_cast<float *>(rec)[S + slot]   = eacc;
-                reinterpret_cast<int *>(rec)[2 * S + slot] = cell_last;
+                reinterpret_cast<RecSlot *>(rec)[slot] = RecSlot{ gacc, eacc, cell_last };
 #endif
                 any_nz    = any_nz | (gacc != 0.0f) | (eacc != 0.0f);
                 if (P.path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
@@ -347,9 +345,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                         const int sg = q / RT_N_SUB, zz = q - sg * RT_N_SUB;
                         const int i2 = backward ? P.N - sg - 1 : sg + 1;
                         const int s2 = (i2 - 1) * RT_N_SUB + (backward ? RT_N_SUB - zz - 1 : zz);
-                        reinterpret_cast<float *>(rec)[s2]       = 0.0f;
-                        reinterpret_cast<float *>(rec)[S + s2]   = 0.0f;
-                        reinterpret_cast<int *>(rec)[2 * S + s2] = 0;
+                        reinterpret_cast<RecSlot *>(rec)[s2] = RecSlot{ 0.0f, 0.0f, 0 };
                     }
                     st = ST_DONE;
                 } else {

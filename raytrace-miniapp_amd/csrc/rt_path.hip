@@ -45,9 +45,9 @@ extern "C" __global__ void __launch_bounds__(256) rt_path_kernel(const DevParams
         const double dvk = P.beam.dv[k];
         dbg[2] += (float) (2 * Iv * dvk); // Helper.h:536-542
         for (int s = 0; s < S; s++) {     // Helper.h:543-566: emission formula per sub-segment
-            const float gs  = reinterpret_cast<const float *>(rec)[s];
-            const float es  = reinterpret_cast<const float *>(rec)[S + s];
-            const int cell  = reinterpret_cast<const int *>(rec)[2 * S + s];
+            const RecSlot sl = reinterpret_cast<const RecSlot *>(rec)[s];
+            const float gs = sl.g, es = sl.e;
+            const int cell = sl.c;
             const float w   = P.gain[s / RT_N_SUB + 1].gv[(size_t) cell * (size_t) P.Kp + (size_t) k];
             const double gl = (double) (gs * w);
             const double el = (double) (es * w);
