@@ -36,16 +36,17 @@ template <> struct alignas(16) FVec<4> { float v[4]; };
 // IEEE operations are replaced by 1-2 ulp equivalents and FMA contraction is allowed.
 #pragma clang fp contract(fast)
 
-// exp(x), <= 2 ulp: x = (64 m + j) ln2/64 + r, |r| <= ln2/128;
-// exp(x) = 2^m * 2^(j/64) * (1 + r + ... + r^5/120)  (remainder r^6/720 < 4e-17).
-// tab[j] = 2^(j/64) lives in LDS.  Overflow -> inf, underflow -> 0, NaN -> NaN.
+// exp(x), <= 2 ulp: x = (256 m + j) ln2/256 + r, |r| <= ln2/512;
+// exp(x) = 2^m * 2^(j/256) * (1 + r + ... + r^5/120)  (remainder r^6/720 < 1e-20).
+// tab[j] = 2^(j/256) lives in LDS.  Overflow -> inf, underflow -> 0, NaN -> NaN.
+constexpr int EXP_TAB = 256;
 __device__ __forceinline__ double exp_tab(double x, const double *tab)
 {
-    const double L2E64 = 92.33248261689366;         // 64 / ln 2
-    const double C_HI  = 0x1.62e42fef00000p-7;      // ln2/64, low 20 bits clear: t*C_HI exact
-    const double C_LO  = 0x1.473de6af278edp-40;
+    const double L2E   = 369.3299304675746;        // 256 / ln 2
+    const double C_HI  = 0x1.62e42fef00000p-9;     // ln2/256, low 20 bits clear: t*C_HI exact
+    const double C_LO  = 0x1.473de6af278edp-42;
     const double xc    = fmin(fmax(x, -1100.0), 1100.0);
-    const double t     = rint(xc * L2E64);
+    const double t     = rint(xc * L2E);
     const int n        = (int) t;
     double r           = fma(-t, C_HI, xc);
     r                  = fma(-t, C_LO, r);
@@ -54,7 +55,7 @@ __device__ __forceinline__ double exp_tab(double x, const double *tab)
     p                  = fma(r, p, 0.5);
     p                  = fma(r, p, 1.0);
     p                  = fma(r, p, 1.0);
-    return ldexp(tab[n & 63] * p, n >> 6); // a NaN argument is clamped away: callers that need it re-test
+    return ldexp(tab[n & (EXP_TAB - 1)] * p, n >> 8); // a NaN argument is clamped away: callers that need it re-test
 }
 
 // a / b to ~1 ulp: hardware reciprocal, one Newton step, one residual correction
@@ -104,38 +105,38 @@ __device__ __forceinline__ double ase_update(double Iv, float gs, float es, floa
 // with gl = (double)(gs*w) exactly as the CPU rounds it (the exponent is where rounding of gl
 // matters) and rs taken once per sub-segment: el/gl = fl(es w)/fl(gs w) = rs (1 + d), |d| <
 // 1.2e-7, a float rounding of the two products that the 1e-5 gate does not resolve.
-// e^gl - 1 is built without cancellation from gl = (64 m + j) ln2/64 + r:
-//     S = 2^m 2^(j/64),  e^r - 1 = r Q(r),  e^gl - 1 = (S - 1) + S r Q(r),
+// e^gl - 1 is built without cancellation from gl = (256 m + j) ln2/256 + r:
+//     S = 2^m 2^(j/256),  e^r - 1 = r Q(r),  e^gl - 1 = (S - 1) + S r Q(r),
 // so one branch-free sequence covers |gl| < 1e-3 (where the CPU switches to a cubic whose
-// own truncation, gl^3/24, is 4e-11) as well as large gains.  The caller keeps |gs * w|
-// <= 708 (DevParams::gs_cap): e^gl stays a normal double, S is assembled by an integer add
-// into the exponent field, and the reduction needs one constant (|64 m + j| < 2^16, so the
-// rounding of ln2/64 moves r by < 6e-14).  A NaN lineshape value gives garbage here; the
-// caller tests for it.  VEC independent chains, table reads issued together.
+// own truncation, gl^3/24, is 4e-11) as well as large gains.  |r| <= ln2/512, so the
+// quadratic Q = 1 + r/2 + r^2/6 is e^r - 1 to 1e-10 -- two orders below the rounding of rs.
+// The caller keeps |gs * w| <= 708 (DevParams::gs_cap): e^gl stays a normal double, S is
+// assembled by an integer add into the exponent field, and the reduction needs one constant
+// (|256 m + j| < 2^18, so the rounding of ln2/256 moves r by < 6e-14).  A NaN lineshape value
+// gives garbage here; the caller tests for it.  VEC independent chains, table reads issued
+// together.
 template <int VEC>
 __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, const double rs, const float (&w)[VEC],
                                          const double *tab)
 {
-    const double L2E64 = 92.33248261689366;  // 64 / ln 2
-    const double LN2_64 = 0.010830424696249145; // ln 2 / 64
-    const double MAGIC = 0x1.8p52;           // adding it leaves rint(.) in the low mantissa bits
+    const double L2E   = 369.3299304675746;     // 256 / ln 2
+    const double LN2_N = 0.0027076061740622863; // ln 2 / 256
+    const double MAGIC = 0x1.8p52;              // adding it leaves rint(.) in the low mantissa bits
     double r[VEC], T[VEC];
     int m[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
         const double x = (double) (gs * w[j]);
-        double t       = fma(x, L2E64, MAGIC);
+        double t       = fma(x, L2E, MAGIC);
         const int n    = __double2loint(t);
         t -= MAGIC;
-        r[j] = fma(-t, LN2_64, x);
-        T[j] = tab[n & 63];
-        m[j] = n >> 6;
+        r[j] = fma(-t, LN2_N, x);
+        T[j] = tab[n & (EXP_TAB - 1)];
+        m[j] = n >> 8;
     }
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-        double q = fma(r[j], 1.0 / 120.0, 1.0 / 24.0);
-        q        = fma(r[j], q, 1.0 / 6.0);
-        q        = fma(r[j], q, 0.5);
+        double q = fma(r[j], 1.0 / 6.0, 0.5);
         q        = fma(r[j], q, 1.0);
         int hi; // exponent field += m in one v_lshl_add_u32 (the compiler's own choice is shift, mask, add)
         asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"(m[j]), "v"(__double2hiint(T[j])));
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
 {
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    __shared__ double exp2_tab[64]; // 2^(j/64), j = 0..63
+    __shared__ double exp2_tab[EXP_TAB]; // 2^(j/256), j = 0..255
     __shared__ __align__(16) double xpose_wg[4 * FREQ_WAVE_XPOSE];
     double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
     const int n_ang  = P.beam.na * P.beam.nb;
@@ -589,8 +590,8 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
     double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (size_t) nslot * (size_t) P.Kp;
     for (int c = (int) threadIdx.x; c < 4 * nslot * P.Kp; c += (int) blockDim.x)
         cache_wg[c] = 0.0;
-    if (threadIdx.x < 64)
-        exp2_tab[threadIdx.x] = exp2((double) threadIdx.x * (1.0 / 64.0));
+    for (int c = (int) threadIdx.x; c < EXP_TAB; c += (int) blockDim.x)
+        exp2_tab[c] = exp2((double) c * (1.0 / EXP_TAB));
     if (lds_iang) {
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x)
             lds_iang[c] = 0.0;

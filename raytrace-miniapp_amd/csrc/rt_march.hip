@@ -202,6 +202,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     }
     const BlobGain *hdr = reinterpret_cast<const BlobGain *>(tab);
 
+    // ends of the three sub-segments of a segment, Helper.h:456: dz * (iz + 1) / N_sub
+    static_assert(RT_N_SUB == 3, "sub-segment ends are tabulated for three sub-segments");
+    const float zs0 = (P.dz0 * (0.0f + 1.0f) / RT_N_SUB), zs1 = (P.dz0 * (1.0f + 1.0f) / RT_N_SUB),
+                zs2 = (P.dz0 * (2.0f + 1.0f) / RT_N_SUB);
+
     unsigned chunk_next = 0, chunk_end = 0; // wave-uniform window of reserved ray indices
     bool more           = true;             // wave-uniform: the global counter is not exhausted
 
@@ -296,7 +301,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
                 z         = 0.0f;
-                z_stop    = (P.dz0 * (0.0f + 1.0f) / RT_N_SUB);
+                z_stop    = zs0;
                 gacc      = 0.0f;
                 eacc      = 0.0f;
                 cell_last = 0;
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     if (seg == L) {
                         st = ST_DONE;
                     } else {
-                        z_stop = (P.dz0 * ((float) iz + 1.0f) / RT_N_SUB);
+                        z_stop = iz == 0 ? zs0 : (iz == 1 ? zs1 : zs2);
                         in_seg = z < 0.995f * z_stop;
                     }
                 }
