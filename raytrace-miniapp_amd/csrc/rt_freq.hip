@@ -311,8 +311,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         }
     }
 
-    double angsum = 0.0;
-    bool bad_neg = false, bad_nan = false;
+    double angsum = 0.0; // RayTraceImageCPU.cpp:63-68, sequential in k like the CPU
+    double iv_min = 0.0; // min over k of Iv, NaNs ignored: negative <=> error -2 (Helper.h:582-594)
     double *img_row = P.image + (size_t) (pix >= 0 ? pix : 0) * (size_t) K;
 
     // The frequency loop, instantiated once per deposit mode (exclusive / few runs / row
@@ -402,14 +402,14 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         Iv[j] *= (gl[j] != gl[j]) ? gl[j] : exp_tab(gl[j], tab);
                 }
             }
+            // No masking here: lanes without a live ray sit in runs of pixel -1, which no deposit
+            // mode flushes, and their error flags and I_ang sum are dropped below; the padding
+            // columns K .. Kp-1 carry w = dv = 0, hence Iv = 0 (deposits test k < K themselves).
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-                const double iv = (live && kb + j < K) ? Iv[j] : 0.0; // columns K .. Kp-1 are padding
-                bad_neg         = bad_neg || iv < 0.0; // Helper.h:582-594
-                bad_nan         = bad_nan || iv != iv;
-                angsum += (2.0 * P.beam.dv[kb + j]) * iv; // RayTraceImageCPU.cpp:66
-                // RayTraceImageCPU.cpp:59, summed over the run of rays that share the pixel
-                Iv[j] = pix >= 0 ? iv * P.scale : 0.0;
+                iv_min = fmin(iv_min, Iv[j]);
+                angsum += (2.0 * P.beam.dv[kb + j]) * Iv[j]; // RayTraceImageCPU.cpp:66
+                Iv[j] = Iv[j] * P.scale;                     // RayTraceImageCPU.cpp:59
             }
 #ifndef RT_ABL_NODEPOSIT
             deposit(kb, Iv);
@@ -563,6 +563,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             }
         }
     }
+    // a NaN intensity makes the I_ang sum NaN (Helper.h:590-593: error -3, after the sign test)
+    const bool bad_neg = iv_min < 0.0, bad_nan = angsum != angsum;
     if (live && (bad_neg || bad_nan)) {
         atomicOr(&P.ctl->failure_code, bad_neg ? (1u << 2) : (1u << 3));
         unsigned slot_f = atomicAdd(&P.ctl->n_failed, 1u);
