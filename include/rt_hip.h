@@ -102,6 +102,13 @@ int rt_hip_device_count(void);
 /* Text of the last HIP failure on this thread ("" if none). */
 const char *rt_hip_last_error(void);
 
+/* Known-answer test of the exact-arithmetic shortcuts of the march on the device itself
+ * (no reference counterpart: the CPU code divides and takes square roots with the IEEE
+ * operators, src/common/RayTraceImageHelper.h:73-89).  Evaluates the shortcut and the IEEE
+ * sequence for every float of the shortcut's range (and a strided sample of all others) and
+ * counts the values where they differ in any bit.  n_mismatch must come back 0. */
+int rt_hip_selftest(int device, unsigned long long *n_checked, unsigned long long *n_mismatch);
+
 /*
  * Host-pointer entry point: what RayTraceImageHipLoop calls.
  * Replaces RayTraceImageCudaLoop (src/RayTraceImageCuda.cu:145-221):

@@ -67,6 +67,12 @@ class HipLibrary:
     def device_count(self) -> int:
         return int(self.lib.rt_hip_device_count())
 
+    def selftest(self, device: int = 0) -> tuple[int, int]:
+        """(values checked, mismatches) of the on-device known-answer test of the march's exact shortcuts."""
+        n, bad = C.c_ulonglong(0), C.c_ulonglong(0)
+        self.check(self.lib.rt_hip_selftest(device, C.byref(n), C.byref(bad)), "rt_hip_selftest")
+        return int(n.value), int(bad.value)
+
     def check(self, rc: int, what: str) -> None:
         if rc != cabi.RT_OK:
             msg = self.lib.rt_hip_last_error().decode(errors="replace")

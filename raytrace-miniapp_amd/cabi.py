@@ -125,6 +125,8 @@ def declare_hip_api(lib: C.CDLL) -> None:
     lib.rt_hip_device_count.restype = C.c_int
     lib.rt_hip_last_error.argtypes = []
     lib.rt_hip_last_error.restype = C.c_char_p
+    lib.rt_hip_selftest.argtypes = [C.c_int, P(C.c_ulonglong), P(C.c_ulonglong)]
+    lib.rt_hip_selftest.restype = C.c_int
     lib.rt_hip_image_loop.argtypes = [
         C.c_int, C.c_int, P(RtBeam), P(RtGain), P(RtSeed), C.c_int, P(RtRay), C.c_size_t,
         C.c_double, c_double_p, c_double_p, P(C.c_uint), P(RtRay), C.c_int, P(C.c_int),
@@ -169,7 +171,7 @@ def declare_hip_api(lib: C.CDLL) -> None:
 
 #: every symbol the header declares -- checked by tests/test_cabi_exports.py
 HIP_API_SYMBOLS = [
-    "rt_hip_device_count", "rt_hip_last_error", "rt_hip_image_loop", "rt_hip_plan_create",
+    "rt_hip_device_count", "rt_hip_last_error", "rt_hip_selftest", "rt_hip_image_loop", "rt_hip_plan_create",
     "rt_hip_plan_set_rays", "rt_hip_plan_set_ray_grid", "rt_hip_plan_run", "rt_hip_plan_fetch",
     "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
     "rt_hip_plan_fetch_probe", "rt_hip_plan_set_step_factor", "rt_hip_plan_enable_path",

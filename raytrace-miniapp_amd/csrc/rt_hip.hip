@@ -306,6 +306,27 @@ int rt_hip_device_count(void)
 
 const char *rt_hip_last_error(void) { return g_last_error.c_str(); }
 
+int rt_hip_selftest(int device, unsigned long long *n_checked, unsigned long long *n_mismatch)
+{
+    if (!n_checked || !n_mismatch)
+        return fail_arg("rt_hip_selftest: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d = nullptr, h[2] = { 0, 0 };
+    HIP_TRY(hipMalloc((void **) &d, sizeof(h)));
+    hipError_t e = hipMemset(d, 0, sizeof(h));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt::rt_selftest_kernel, dim3(1024), dim3(256), 0, nullptr, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    HIP_TRY(e);
+    *n_checked  = h[0];
+    *n_mismatch = h[1];
+    return RT_OK;
+}
+
 void rt_hip_plan_destroy(rt_hip_plan *p)
 {
     if (!p)

@@ -138,6 +138,28 @@ extern "C" __global__ void __launch_bounds__(256) rt_seed_tab_kernel(const DevSe
     }
 }
 
+// rt_hip_selftest: inv_norm against the IEEE sequence, bit for bit, for every float of its
+// shortcut range and every 256th bit pattern elsewhere
+extern "C" __global__ void __launch_bounds__(256) rt_selftest_kernel(unsigned long long *counts)
+{
+    const unsigned lo = 0x3f700000u, hi = 0x3f880000u; // [0.9375, 1.0625)
+    const unsigned n_fast = hi - lo, n_other = 1u << 24;
+    unsigned long long checked = 0, bad = 0;
+    for (unsigned long long t = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; t < (unsigned long long) n_fast + n_other;
+         t += (unsigned long long) gridDim.x * blockDim.x) {
+        const unsigned u = t < n_fast ? lo + (unsigned) t : (unsigned) (t - n_fast) << 8;
+        float q          = __uint_as_float(u);
+        const float a    = inv_norm(q);
+        asm volatile("" : "+v"(q));
+        const float b = 1.0f / sqrtf(q);
+        checked++;
+        if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b))
+            bad++;
+    }
+    atomicAdd(&counts[0], checked);
+    atomicAdd(&counts[1], bad);
+}
+
 // list mode: tangents of the launch angles (Helper.h:409-410) for every ray, at full lane
 // occupancy, before the march
 extern "C" __global__ void __launch_bounds__(256) rt_tan_kernel(const rt_ray *rays, unsigned long long n, float *sxy)

@@ -71,14 +71,41 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 // 2^-54 of a 25-bit midpoint, which a 24-bit y cannot produce unless it is a
 // power of two, where both are exact) -- checked exhaustively for y in
 // [0.25, 4) by tests/test_float_identities.py.
+//
+// inv_norm computes that float without the two IEEE sequences (17 + 11 VALU) when q is near
+// 1, where a direction vector's squared norm always is: y = v_rsq_f32(q) (1 ulp), one
+// Markstein step for the root, s1 = RN(s0 + (q - s0^2) y/2) with s0 = RN(q y), one Newton
+// step for its reciprocal from the same y, RN(y + y (1 - s1 y)); a root whose significand is
+// all ones -- the one case the Newton step can miss, and a common one (q just below 1) -- has
+// the closed form RN(1/s1) = bits(0x7f000000 - bits(s1)).  tests/test_float_identities.py
+// checks the sequence against 1.0f / sqrtf(q) for every q in [0.9375, 1.0625) and every y
+// within 1 ulp of 1/sqrt(q); rt_hip_selftest checks it on the device itself for every q.
+__device__ __forceinline__ float inv_norm(float q)
+{
+    float inv;
+#ifdef RT_ABL_FASTDIV
+    inv = __builtin_amdgcn_rsqf(q);
+#else
+    if (fabsf(q - 1.0f) < 0.0625f) {
+        const float y    = __builtin_amdgcn_rsqf(q);
+        const float s0   = q * y;
+        const float e    = fmaf(-s0, s0, q);
+        const float s1   = fmaf(e, 0.5f * y, s0); // = sqrtf(q)
+        const float r    = fmaf(-s1, y, 1.0f);
+        inv              = fmaf(r, y, y);
+        const unsigned u = __float_as_uint(s1);
+        inv              = ((u & 0x7fffffu) == 0x7fffffu) ? __uint_as_float(0x7f000000u - u) : inv;
+    } else {
+        asm volatile("" : "+v"(q)); // keep the general case behind its branch
+        inv = 1.0f / sqrtf(q);
+    }
+#endif
+    return inv;
+}
 __device__ __forceinline__ void renormalise(float &sx, float &sy, float &sz)
 {
     float q   = sx * sx + sy * sy + sz * sz;
-#ifdef RT_ABL_FASTDIV
-    float inv = __builtin_amdgcn_rsqf(q);
-#else
-    float inv = 1.0f / sqrtf(q);
-#endif
+    float inv = inv_norm(q);
     sx *= inv;
     sy *= inv;
     sz *= inv;

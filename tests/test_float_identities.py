@@ -143,6 +143,61 @@ def test_division_by_correctly_rounded_reciprocal_is_ieee_division(tmp_path):
     assert lib.check(20_000_000, 97) == 0
 
 
+_INV_NORM_C = r"""
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+static float fb(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t bf(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+/* rt_math.h, inv_norm: the shortcut branch, with y standing for the result of v_rsq_f32 */
+static float inv_norm_fast(float q, float y)
+{
+    const float s0 = q * y;
+    const float e  = fmaf(-s0, s0, q);
+    const float s1 = fmaf(e, 0.5f * y, s0);
+    const float r  = fmaf(-s1, y, 1.0f);
+    float inv      = fmaf(r, y, y);
+    const uint32_t u = bf(s1);
+    if ((u & 0x7fffffu) == 0x7fffffu) inv = fb(0x7f000000u - u);
+    return inv;
+}
+/* every q with |q - 1| < 0.0625, every float y within 1 ulp of 1/sqrt(q) (the accuracy the ISA
+ * states for v_rsq_f32): mismatches against the reference's 1.0f / sqrtf(q) */
+long check(void)
+{
+    long bad = 0;
+    for (uint32_t u = bf(0.9375f); u <= bf(1.0625f); u++) {
+        const float q = fb(u);
+        if (!(fabsf(q - 1.0f) < 0.0625f)) continue;
+        const float want = 1.0f / sqrtf(q);
+        const double ex  = 1.0 / sqrt((double) q);
+        const float yt   = (float) ex;
+        for (int k = -1; k <= 1; k++) {
+            const float y   = fb(bf(yt) + k);
+            const double ul = (double) fb(bf(yt) + 1) - (double) yt;
+            if (fabs((double) y - ex) > ul) continue;
+            if (bf(inv_norm_fast(q, y)) != bf(want)) bad++;
+        }
+    }
+    return bad;
+}
+"""
+
+
+def test_inv_norm_shortcut_equals_ieee_sqrt_and_division(tmp_path):
+    """rt_math.h inv_norm: rsq + one Markstein step + one Newton step (+ the all-ones closed form)
+    against 1.0f / sqrtf(q) over the whole shortcut range, for any 1-ulp rsq result."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "inv.c"
+    src.write_text(_INV_NORM_C)
+    so = tmp_path / "libinv.so"
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src), "-lm"], check=True)
+    lib = ctypes.CDLL(str(so))
+    lib.check.restype = ctypes.c_long
+    assert lib.check() == 0
+
+
 def test_float_thresholds_equal_the_double_comparisons():
     """rt_march.hip compares in float where the reference compares a widened float with
     a double literal: (double)x < 0.05 <=> x < 0.05f (Helper.h:280) and

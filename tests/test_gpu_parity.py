@@ -77,3 +77,11 @@ def test_seed_small_march_record_bit_exact(hip, oracle, seed_small):
         pr = plan.fetch_probe()
     ora = oracle.probe(seed_small, rays, want_Iv=False)
     _check_probe(pr, ora)
+
+
+def test_selftest_of_exact_shortcuts_on_the_device(hip):
+    """inv_norm (rsq + Markstein + Newton) against the IEEE sqrt/division sequence on the device
+    itself: every float of the shortcut range, every 256th bit pattern elsewhere."""
+    n, bad = hip.HipLibrary.get().selftest(0)
+    assert n == (0x3f880000 - 0x3f700000) + (1 << 24)
+    assert bad == 0
