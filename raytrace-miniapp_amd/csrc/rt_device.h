@@ -93,7 +93,10 @@ struct DevRays {
 // Per-ray march record, one per ray at rec + ridx * rec_stride:
 //   RecSlot slot[S];    {gvl, evl, ivl} of each sub-segment, S = (N-1)*3, Helper.h:386-388
 //                       (one 12-byte store when a sub-segment ends)
-//   RecMeta meta;       exit position / direction, flags | steps << 8
+//   RecMeta meta;       exit position / direction, flags | n_done << 4 | steps << 12
+// Only the first n_done sub-segments in marching order were entered and have their slot written
+// (an escaped ray stops early, Helper.h:465-469, 505-511); readers take the others as zero:
+// rec_slot() below.  Forward march: slots 0 .. n_done-1, backward: S-n_done .. S-1.
 // rec_stride = round16(12 S + 24).
 struct RecSlot {
     float g, e; // sum of g0 * path, E0 * path over the cells of the sub-segment
@@ -165,6 +168,9 @@ struct DevParams {
     // pass, so that gs * gv never leaves the range where e^x is a normal double (rt_freq.hip)
 };
 
+// packing of RecMeta::flags_steps
+constexpr unsigned REC_FLAG_MASK = 0xfu, REC_NDONE_SHIFT = 4, REC_NDONE_MASK = 0xffu, REC_STEPS_SHIFT = 12;
+
 // flag bits of the per-ray march record
 enum : unsigned {
     F_ESCAPED = 1u, // left the plasma (Helper.h:465-469)
@@ -172,5 +178,17 @@ enum : unsigned {
     F_SKIP    = 4u, // frequency pass provably contributes exactly zero
     F_VALID   = 8u  // lane holds a ray of this tile
 };
+
+// slot s of a record, zero if the ray never entered that sub-segment
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline RecSlot rec_slot(const unsigned char *rec, int s, int S, unsigned flags_steps, bool backward)
+{
+    const int n_done   = (int) ((flags_steps >> REC_NDONE_SHIFT) & REC_NDONE_MASK);
+    const bool written = backward ? s >= S - n_done : s < n_done;
+    RecSlot z          = { 0.0f, 0.0f, 0 };
+    return written ? reinterpret_cast<const RecSlot *>(rec)[s] : z;
+}
 
 } // namespace rt

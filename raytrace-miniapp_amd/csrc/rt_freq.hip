@@ -200,8 +200,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     RecMeta m   = { 0, 0, 0, 0, 1, 0 };
     if (have) {
         m     = *reinterpret_cast<const RecMeta *>(rec + 12 * (size_t) S);
-        fl    = m.flags_steps & 0xffu;
-        steps = m.flags_steps >> 8;
+        fl    = m.flags_steps & REC_FLAG_MASK;
+        steps = m.flags_steps >> REC_STEPS_SHIFT;
         float ta, tb;
         load_ray(P.rays, ridx, ray, ta, tb, false);
     }
@@ -301,7 +301,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     if (SF) {
 #pragma unroll
         for (int s = 0; s < SF; s++) {
-            const RecSlot sl = reinterpret_cast<const RecSlot *>(rec)[s];
+            const RecSlot sl = rec_slot(rec, s, SF, m.flags_steps, P.method == 1);
             gs[s]            = sl.g;
             const float e1   = sl.e;
             cs[s]            = sl.c;
@@ -347,7 +347,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         if (fabsf(gs[s]) >= RT_RS_MIN) {
                             ase_step<VEC>(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
-                            const float e1 = reinterpret_cast<const RecSlot *>(rec)[s].e;
+                            const float e1 = rec_slot(rec, s, SF, m.flags_steps, P.method == 1).e;
                             if (gs[s] != 0.0f || e1 != 0.0f) { // else the update is the identity
 #pragma unroll
                                 for (int j = 0; j < VEC; j++)
@@ -357,7 +357,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     }
                 } else {
                     for (int s = 0; s < S; s++) {
-                        const RecSlot sl = reinterpret_cast<const RecSlot *>(rec)[s];
+                        const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, P.method == 1);
                         const float g1 = sl.g, e1 = sl.e;
                         const int c1   = sl.c;
                         const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
@@ -386,8 +386,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     gl[j] = 0.0;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    const float g1    = SF ? gs[SF ? s : 0] : reinterpret_cast<const RecSlot *>(rec)[s].g;
-                    const int c1      = SF ? cs[SF ? s : 0] : reinterpret_cast<const RecSlot *>(rec)[s].c;
+                    const float g1    = SF ? gs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).g;
+                    const int c1      = SF ? cs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).c;
                     const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
                     const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
 #pragma unroll

@@ -933,14 +933,15 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
             HIP_TRY(hipMemcpy(h.data(), p->rec, h.size(), hipMemcpyDeviceToHost));
         for (size_t r = 0; r < n; r++) {
             const unsigned char *rec = h.data() + r * p->P.rec_stride;
-            const rt::RecSlot *sl = reinterpret_cast<const rt::RecSlot *>(rec);
+            const rt::RecMeta *mt = reinterpret_cast<const rt::RecMeta *>(rec + 12 * S);
             for (size_t q = 0; q < S; q++) {
+                const rt::RecSlot sl = rt::rec_slot(rec, (int) q, (int) S, mt->flags_steps, p->P.method == 1);
                 if (gvl)
-                    gvl[r * S + q] = sl[q].g;
+                    gvl[r * S + q] = sl.g;
                 if (evl)
-                    evl[r * S + q] = sl[q].e;
+                    evl[r * S + q] = sl.e;
                 if (ivl)
-                    ivl[r * S + q] = sl[q].c;
+                    ivl[r * S + q] = sl.c;
             }
         }
     }

@@ -226,8 +226,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 
     // ends of the three sub-segments of a segment, Helper.h:456: dz * (iz + 1) / N_sub
     static_assert(RT_N_SUB == 3, "sub-segment ends are tabulated for three sub-segments");
-    const float zs0 = (P.dz0 * (0.0f + 1.0f) / RT_N_SUB), zs1 = (P.dz0 * (1.0f + 1.0f) / RT_N_SUB),
-                zs2 = (P.dz0 * (2.0f + 1.0f) / RT_N_SUB);
+    // (made opaque: otherwise the optimiser turns the later select of quotients back into a
+    // division of selected dividends)
+    float zs0 = (P.dz0 * (0.0f + 1.0f) / RT_N_SUB), zs1 = (P.dz0 * (1.0f + 1.0f) / RT_N_SUB),
+          zs2 = (P.dz0 * (2.0f + 1.0f) / RT_N_SUB);
+    asm volatile("" : "+v"(zs0), "+v"(zs1), "+v"(zs2));
 
     unsigned chunk_next = 0, chunk_end = 0; // wave-uniform window of reserved ray indices
     bool more           = true;             // wave-uniform: the global counter is not exhausted
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     float z = 0.0f, z_stop = 0.0f;
     float px = 0, py = 0, pz = 0, sx = 0, sy = 0, sz = 1;
     float gacc = 0, eacc = 0;
-    int cell_last = 0;
+    int cell_last = 0, n_done = 0;
     unsigned steps = 0;
     bool escaped = false, any_nz = false, mirror = false;
     // cell (corner values are re-read from the blob in block [B])
@@ -367,13 +370,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 eacc      = 0.0f;
                 cell_last = 0;
                 if (escaped) {
-                    // the remaining sub-segments are never entered: their slots stay zero
-                    for (int q = seg * RT_N_SUB + iz + 1; q < S; q++) {
-                        const int sg = q / RT_N_SUB, zz = q - sg * RT_N_SUB;
-                        const int i2 = backward ? P.N - sg - 1 : sg + 1;
-                        const int s2 = (i2 - 1) * RT_N_SUB + (backward ? RT_N_SUB - zz - 1 : zz);
-                        reinterpret_cast<RecSlot *>(rec)[s2] = RecSlot{ 0.0f, 0.0f, 0 };
-                    }
+                    // the remaining sub-segments are never entered: RecMeta::n_done tells the readers
+                    n_done = seg * RT_N_SUB + iz + 1;
                     st = ST_DONE;
                 } else {
                     if (++iz == RT_N_SUB) {
@@ -383,7 +381,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                         z  = 0.0f;
                     }
                     if (seg == L) {
-                        st = ST_DONE;
+                        n_done = S;
+                        st     = ST_DONE;
                     } else {
                         z_stop = iz == 0 ? zs0 : (iz == 1 ? zs1 : zs2);
                         in_seg = z < 0.995f * z_stop;
@@ -475,7 +474,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 m.sx          = sx;
                 m.sy          = sy;
                 m.sz          = sz;
-                m.flags_steps = fl | (steps << 8);
+                m.flags_steps = fl | ((unsigned) n_done << REC_NDONE_SHIFT) | (steps << REC_STEPS_SHIFT);
                 *reinterpret_cast<RecMeta *>(rec + 12 * (size_t) S) = m;
                 tot_steps += steps;
                 tot_esc += escaped ? 1u : 0u;
