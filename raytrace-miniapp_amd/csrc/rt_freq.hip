@@ -3,8 +3,8 @@
 // RayTraceImageCPU.cpp:37-68) with lanes = rays.
 //
 // One wavefront owns a tile of 64 consecutive rays; lane r integrates ray r over
-// all K frequencies, VEC frequencies at a time (VEC independent dependency chains
-// per lane; the lineshape row gv[cell][k..k+VEC) is one 4*VEC-byte load per
+// all K frequencies, VEC = 4 frequencies at a time (four independent dependency chains
+// per lane; the lineshape row gv[cell][k..k+4) is one 16-byte load per
 // sub-segment).  Every lane is busy for the whole tile -- the regular half of the
 // path sees none of the march's divergence -- and the two reductions of the
 // deposit become cheap:
@@ -24,10 +24,8 @@ namespace rt {
 #define RT_FREQ_WAVES 3 // waves per SIMD the frequency kernel is compiled for (<= 168 VGPRs; 4 spills)
 #endif
 
-template <int VEC> struct FVec;
-template <> struct FVec<1> { float v[1]; };
-template <> struct alignas(8) FVec<2> { float v[2]; };
-template <> struct alignas(16) FVec<4> { float v[4]; };
+constexpr int VEC = 4; // frequencies per lane and pass; rows are padded to a multiple (DevParams::Kp)
+struct alignas(16) FVec { float v[VEC]; };
 
 // ---- float64 building blocks of the frequency pass ---------------------------------
 // The frequency pass is the float64 half of the path; its results are compared with
@@ -67,9 +65,9 @@ __device__ __forceinline__ double div_fast(double a, double b)
     return fma(fma(-b, q, a), y, q);
 }
 
-// Sum of v over the 64 lanes, valid in lane 63: four row_shr steps inside each row of
-// 16 lanes, then row_bcast:15 / row_bcast:31 across rows -- DPP moves (VALU latency)
-// instead of ds_bpermute round trips through the LDS crossbar.
+// v + (v moved by one DPP control): the building block of the in-register reductions (row_shr
+// trees inside a row of 16 lanes, quad_perm exchanges) -- VALU latency instead of ds_bpermute
+// round trips through the LDS crossbar.
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_step(double v)
 {
     const int lo  = __double2loint(v), hi = __double2hiint(v);
@@ -77,17 +75,6 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_step(dou
     const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
     return v + __hiloint2double(thi, tlo);
 }
-__device__ __forceinline__ double wave_total_lane63(double v)
-{
-    v = dpp_step<0x111, 0xf>(v); // row_shr:1
-    v = dpp_step<0x112, 0xf>(v); // row_shr:2
-    v = dpp_step<0x114, 0xf>(v); // row_shr:4
-    v = dpp_step<0x118, 0xf>(v); // row_shr:8  -> lane 15 of each row holds the row sum
-    v = dpp_step<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
-    v = dpp_step<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> lane 63 = total
-    return v;
-}
-
 // Helper.h:549-557, one (sub-segment, frequency) update with emission, as the CPU writes it
 // (kept for the sub-segments whose gain sum is zero or denormal-small, see ase_step)
 __device__ __forceinline__ double ase_update(double Iv, float gs, float es, float w, const double *tab)
@@ -115,7 +102,6 @@ __device__ __forceinline__ double ase_update(double Iv, float gs, float es, floa
 // (|256 m + j| < 2^18, so the rounding of ln2/256 moves r by < 6e-14).  A NaN lineshape value
 // gives garbage here; the caller tests for it.  VEC independent chains, table reads issued
 // together.
-template <int VEC>
 __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, const double rs, const float (&w)[VEC],
                                          const double *tab)
 {
@@ -180,7 +166,7 @@ constexpr int XP_ROW          = 66;
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
 
-template <int SF, int VEC>
+template <int SF>
 __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const double *tab, double *xpose,
                                           double *cache, const int nslot, const unsigned tile, const int lane)
 {
@@ -329,7 +315,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     wnan[j] = false;
                 }
                 if (SF) {
-                    FVec<VEC> w[SF ? SF : 1];
+                    FVec w[SF ? SF : 1];
 #pragma unroll
                     for (int s = 0; s < SF; s++) {
 #ifdef RT_ABL_NOLOAD
@@ -337,7 +323,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #else
                         const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) Kp + kb;
 #endif
-                        w[s] = *reinterpret_cast<const FVec<VEC> *>(row);
+                        w[s] = *reinterpret_cast<const FVec *>(row);
                     }
 #pragma unroll
                     for (int s = 0; s < SF; s++) {
@@ -345,7 +331,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         for (int j = 0; j < VEC; j++)
                             wnan[j] = wnan[j] || w[s].v[j] != w[s].v[j];
                         if (fabsf(gs[s]) >= RT_RS_MIN) {
-                            ase_step<VEC>(Iv, gs[s], rs[s], w[s].v, tab);
+                            ase_step(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
                             const float e1 = rec_slot(rec, s, SF, m.flags_steps, P.method == 1).e;
                             if (gs[s] != 0.0f || e1 != 0.0f) { // else the update is the identity
@@ -361,13 +347,13 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                         const float g1 = sl.g, e1 = sl.e;
                         const int c1   = sl.c;
                         const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
-                        const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+                        const FVec w = *reinterpret_cast<const FVec *>(row);
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
                             wnan[j] = wnan[j] || w.v[j] != w.v[j];
                         if (fabsf(g1) >= RT_RS_MIN) {
                             const double r1 = div_fast((double) e1, (double) g1);
-                            ase_step<VEC>(Iv, __builtin_amdgcn_fmed3f(g1, -P.gs_cap, P.gs_cap), r1, w.v, tab);
+                            ase_step(Iv, __builtin_amdgcn_fmed3f(g1, -P.gs_cap, P.gs_cap), r1, w.v, tab);
                         } else if (g1 != 0.0f || e1 != 0.0f) {
 #pragma unroll
                             for (int j = 0; j < VEC; j++)
@@ -389,7 +375,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     const float g1    = SF ? gs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).g;
                     const int c1      = SF ? cs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).c;
                     const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
-                    const FVec<VEC> w = *reinterpret_cast<const FVec<VEC> *>(row);
+                    const FVec w = *reinterpret_cast<const FVec *>(row);
 #pragma unroll
                     for (int j = 0; j < VEC; j++)
                         gl[j] += (double) g1 * (double) w.v[j];
@@ -417,11 +403,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         }
     };
 
-#ifdef RT_ABL_ONLY_FEW
-    if (false) {
-#else
     if (excl_all) {
-#endif
         // one ray per pixel: plain stores of the row, no reduction, no atomics
         frequency_loop([&](int kb, double (&v)[VEC]) {
 #pragma unroll
@@ -432,12 +414,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     unsafeAtomicAdd(&img_row[kb + j], v[j]);
             }
         });
-#ifdef RT_ABL_ONLY_FEW
-    } else if (true) {
-#else
     } else if (few) {
-#endif
-        // Per run and frequency one sum over the wave.  VEC = 4: the lanes park their four
+        // Per run and frequency one sum over the wave: the lanes park their four
         // values in the wave's LDS scratch [4][XP_ROW], lane (j, p) = (lane / 16, lane % 16)
         // adds four neighbours of frequency j, a row_shr tree inside the row of 16 lanes
         // finishes the sum (15 VALU operations for 4 frequencies instead of 4 x 18 for four
@@ -453,32 +431,19 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         }
         const bool single = n_runs == 1;
         auto wave_sums    = [&](const int q, const int kb, double (&v)[VEC], const bool masked) {
-#ifdef RT_ABL_DPP
-            if (false) {
-#else
-            if (VEC == 4) {
-#endif
 #pragma unroll
-                for (int j = 0; j < VEC; j++)
-                    xpose[j * XP_ROW + lane] = (!masked || run_id == q) ? v[j] : 0.0;
-                __builtin_amdgcn_wave_barrier();
-                const double *src = xpose + (lane >> 4) * XP_ROW + 4 * (lane & 15);
-                double t          = (src[0] + src[1]) + (src[2] + src[3]);
-                __builtin_amdgcn_wave_barrier();
-                t = dpp_step<0x111, 0xf>(t);
-                t = dpp_step<0x112, 0xf>(t);
-                t = dpp_step<0x114, 0xf>(t);
-                t = dpp_step<0x118, 0xf>(t);
-                if ((lane & 15) == 15)
-                    win[q * WAVE + ((kb + (lane >> 4)) & (WAVE - 1))] = t;
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    const double t = wave_total_lane63((!masked || run_id == q) ? v[j] : 0.0);
-                    if (lane == WAVE - 1)
-                        win[q * WAVE + ((kb + j) & (WAVE - 1))] = t;
-                }
-            }
+            for (int j = 0; j < VEC; j++)
+                xpose[j * XP_ROW + lane] = (!masked || run_id == q) ? v[j] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            const double *src = xpose + (lane >> 4) * XP_ROW + 4 * (lane & 15);
+            double t          = (src[0] + src[1]) + (src[2] + src[3]);
+            __builtin_amdgcn_wave_barrier();
+            t = dpp_step<0x111, 0xf>(t);
+            t = dpp_step<0x112, 0xf>(t);
+            t = dpp_step<0x114, 0xf>(t);
+            t = dpp_step<0x118, 0xf>(t);
+            if ((lane & 15) == 15)
+                win[q * WAVE + ((kb + (lane >> 4)) & (WAVE - 1))] = t;
         };
         frequency_loop([&](int kb, double (&v)[VEC]) {
             if (single) {
@@ -579,7 +544,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     }
 }
 
-template <int SF, int VEC>
+template <int SF>
 __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
 {
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
@@ -607,7 +572,7 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
         tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
         if (tile >= P.n_tiles)
             break;
-        freq_tile<SF, VEC>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
+        freq_tile<SF>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
     }
     if (lds_iang) {
         __syncthreads();

@@ -180,8 +180,8 @@ struct rt_hip_plan {
 };
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
-// the shipped inputs; 0 = any N), VEC = frequencies per lane per pass
-template <int SF, int VEC>
+// the shipped inputs; 0 = any N)
+template <int SF>
 static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
@@ -209,7 +209,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         cap = cap_blocks;
     const unsigned grid = (unsigned) (want < cap ? want : cap);
     if (grid > 0) {
-        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, VEC>), dim3(grid), dim3(256), lds, stream, p->P, in_lds, nslot);
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF>), dim3(grid), dim3(256), lds, stream, p->P, in_lds, nslot);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
@@ -286,7 +286,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     } else if (!(p->P.debug & 1u)) {
         const int S = p->P.L * RT_N_SUB;
         int rc;
-        rc = (S == 6) ? launch_freq<6, 4>(p, stream, 0) : launch_freq<0, 4>(p, stream, 0);
+        rc = (S == 6) ? launch_freq<6>(p, stream, 0) : launch_freq<0>(p, stream, 0);
         if (rc != RT_OK)
             return rc;
     }
