@@ -56,6 +56,38 @@ __device__ __forceinline__ double exp_tab(double x, const double *tab)
     return ldexp(tab[n & (EXP_TAB - 1)] * p, n >> 8); // a NaN argument is clamped away: callers that need it re-test
 }
 
+// The same kernel for VEC arguments at once: the four chains advance in lock step (the table
+// reads are issued together), rint comes from the magic-constant add.  e^x of a NaN is NaN.
+__device__ __forceinline__ void exp_tab_vec(const double (&x)[VEC], const double *tab, double (&e)[VEC])
+{
+    const double L2E   = 369.3299304675746;
+    const double C_HI  = 0x1.62e42fef00000p-9;
+    const double C_LO  = 0x1.473de6af278edp-42;
+    const double MAGIC = 0x1.8p52; // adding it leaves rint(.) in the low mantissa bits
+    double r[VEC], T[VEC];
+    int m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const double xc = fmin(fmax(x[j], -1100.0), 1100.0);
+        double t        = fma(xc, L2E, MAGIC);
+        const int n     = __double2loint(t);
+        t -= MAGIC;
+        r[j] = fma(-t, C_HI, xc);
+        r[j] = fma(-t, C_LO, r[j]);
+        T[j] = tab[n & (EXP_TAB - 1)];
+        m[j] = n >> 8;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        double p = fma(r[j], 1.0 / 24.0, 1.0 / 6.0); // |r| <= ln2/512: the r^5/120 term is below 4e-17
+        p        = fma(r[j], p, 0.5);
+        p        = fma(r[j], p, 1.0);
+        p        = fma(r[j], p, 1.0);
+        const double v = ldexp(T[j] * p, m[j]);
+        e[j]           = x[j] != x[j] ? x[j] : v;
+    }
+}
+
 // a / b to ~1 ulp: hardware reciprocal, one Newton step, one residual correction
 __device__ __forceinline__ double div_fast(double a, double b)
 {
@@ -264,21 +296,37 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         ang = -1;
     }
 
-    // ---- runs of equal pixel index (built once per tile) --------------------------
-    // Few runs (ASE: a tile lies inside one pixel, or straddles two): one DPP wave sum per
-    // run and frequency, totals parked in lane (k mod 64) and flushed as ONE coalesced atomic
-    // per run and 64 frequencies.  More runs (seeded mode: ~7 per tile): every run owns one
-    // row of the wave's LDS row cache [nslot][K]; lanes add into their run's row with LDS f64
-    // atomics, rows are flushed per tile with coalesced atomics.  Beyond the cache: a
-    // segmented shuffle scan.
+    // ---- pixels of the tile (built once per tile) ----------------------------------
+    // Few runs of equal pixel (ASE: a tile lies inside one pixel, or straddles two): one wave
+    // sum per run and frequency, totals flushed as ONE coalesced atomic per run and 64
+    // frequencies.  Otherwise (seeded mode: 4..8 pixels per tile): every distinct pixel owns one
+    // row of the wave's LDS row cache [nslot][Kp]; lanes add into their pixel's row with LDS f64
+    // atomics, rows are flushed per tile with coalesced atomics.  More distinct pixels than
+    // rows: a segmented shuffle scan over the runs.
     constexpr int MAXQ               = FREQ_MAXQ;
     const int pix_before             = __shfl_up(pix, 1, WAVE);
     const unsigned long long head_m  = __ballot(lane == 0 || pix_before != pix);
     const int n_runs                 = (int) __popcll(head_m);
     const bool few                   = n_runs <= MAXQ;
-    const bool cached                = !few && n_runs <= nslot;
     const unsigned long long le_mask = (lane == WAVE - 1) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
     const int run_id                 = (int) __popcll(head_m & le_mask) - 1;
+    // distinct pixels -> cache rows: the first unassigned lane names a pixel, every lane with
+    // that pixel takes the row; lane q keeps the pixel of row q for the flush
+    int slot = -1, slot_pix = -1, n_slots = 0;
+    bool cached = false;
+    if (!few && nslot > 0) {
+        unsigned long long rem = __ballot(pix >= 0);
+        while (rem != 0ull && n_slots < nslot) {
+            const int p = __builtin_amdgcn_readlane(pix, (int) __ffsll((long long) rem) - 1);
+            if (pix == p)
+                slot = n_slots;
+            if (lane == n_slots)
+                slot_pix = p;
+            rem &= ~__ballot(pix == p);
+            n_slots++;
+        }
+        cached = rem == 0ull;
+    }
 
     // ---- the march record of this lane's ray ---------------------------------------
     float gs[SF ? SF : 1];
@@ -380,12 +428,21 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     for (int j = 0; j < VEC; j++)
                         gl[j] += (double) g1 * (double) w.v[j];
                 }
+                // Iv = f0 f[4][k] exp(gl); for f0 = 0 that is exactly 0 unless exp overflows (0 * inf):
+                // a wave none of whose lanes needs the exponential skips it
+                bool need = f0 != 0.0;
 #pragma unroll
-                for (int j = 0; j < VEC; j++) {
+                for (int j = 0; j < VEC; j++)
+                    need = need || gl[j] > 700.0 || gl[j] != gl[j];
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
                     Iv[j] = f0 * P.seed.f[4][kb + j];
-                    // 0 * exp(gl) is exactly 0 unless exp overflows: skip the exp then
-                    if (f0 != 0.0 || gl[j] > 700.0)
-                        Iv[j] *= (gl[j] != gl[j]) ? gl[j] : exp_tab(gl[j], tab);
+                if (__ballot(need) != 0ull) {
+                    double eg[VEC];
+                    exp_tab_vec(gl, tab, eg);
+#pragma unroll
+                    for (int j = 0; j < VEC; j++)
+                        Iv[j] *= eg[j];
                 }
             }
             // No masking here: lanes without a live ray sit in runs of pixel -1, which no deposit
@@ -468,13 +525,13 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             }
         });
     } else if (cached) {
-        // LDS atomics serialise on equal addresses (the lanes of one run): quads that lie inside
-        // one run add their four values with two quad_perm DPP steps and send one atomic
-        double *my_row      = cache + (size_t) run_id * (size_t) Kp;
-        const int rid_first = __builtin_amdgcn_update_dpp(0, run_id, 0x00, 0xf, 0xf, true); // quad_perm:[0,0,0,0]
-        const int rid_last  = __builtin_amdgcn_update_dpp(0, run_id, 0xff, 0xf, 0xf, true); // quad_perm:[3,3,3,3]
-        const bool quad_one = rid_first == rid_last; // run ids do not decrease along the lanes
-        const bool sender   = pix >= 0 && (!quad_one || (lane & 3) == 0);
+        // LDS atomics serialise on equal addresses (the lanes of one pixel): quads whose four
+        // lanes share a pixel add their values with two quad_perm DPP steps and send one atomic
+        double *my_row       = cache + (size_t) (slot >= 0 ? slot : 0) * (size_t) Kp;
+        const int slot_first = __builtin_amdgcn_update_dpp(0, slot, 0x00, 0xf, 0xf, true); // quad_perm:[0,0,0,0]
+        const unsigned long long same = __ballot(slot == slot_first);
+        const bool quad_one  = ((same >> (lane & ~3)) & 0xfull) == 0xfull;
+        const bool sender    = slot >= 0 && (!quad_one || (lane & 3) == 0);
         frequency_loop([&](int kb, double (&v)[VEC]) {
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
@@ -513,14 +570,9 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         });
     }
     if (cached) {
-        // flush this tile's rows: one coalesced run of atomics per pixel run, rows re-zeroed
-        unsigned long long mm = head_m;
-        for (int q = 0; q < n_runs; q++) {
-            const int l  = (int) __ffsll((long long) mm) - 1;
-            const int pq = __builtin_amdgcn_readlane(pix, l);
-            mm &= mm - 1;
-            if (pq < 0)
-                continue;
+        // flush this tile's rows: one coalesced run of atomics per pixel, rows re-zeroed
+        for (int q = 0; q < n_slots; q++) {
+            const int pq = __builtin_amdgcn_readlane(slot_pix, q);
             for (int k = lane; k < K; k += WAVE) {
                 const double v = cache[q * Kp + k];
                 cache[q * Kp + k] = 0.0;
