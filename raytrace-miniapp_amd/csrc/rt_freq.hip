@@ -20,6 +20,9 @@
 
 namespace rt {
 
+#ifndef RT_FREQ_WAVES_SEED
+#define RT_FREQ_WAVES_SEED 4 // the gain-only instance keeps far less per-lane state
+#endif
 #ifndef RT_FREQ_WAVES
 #define RT_FREQ_WAVES 3 // waves per SIMD the frequency kernel is compiled for (<= 168 VGPRs; 4 spills)
 #endif
@@ -198,7 +201,7 @@ constexpr int XP_ROW          = 66;
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
 
-template <int SF>
+template <int SF, bool EMIS>
 __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const double *tab, double *xpose,
                                           double *cache, const int nslot, const unsigned tile, const int lane)
 {
@@ -210,7 +213,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     const unsigned ridx   = tile * WAVE + (unsigned) lane;
     const bool have       = ridx < n_rays;
     const unsigned char *rec = P.rec + (size_t) (have ? ridx : 0) * P.rec_stride;
-    const bool use_emis   = P.use_emis != 0;
+    constexpr bool use_emis = EMIS; // Helper.h:402, fixed per kernel instance (see launch_freq)
 
     // ---- per-ray preamble: exit ray, seed factor, deposit cells ------------------
     unsigned fl = 0, steps = 0;
@@ -596,8 +599,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     }
 }
 
-template <int SF>
-__global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
+template <int SF, bool EMIS>
+__global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
 {
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -624,7 +627,7 @@ __global__ void __launch_bounds__(256, RT_FREQ_WAVES) rt_freq_kernel(const DevPa
         tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
         if (tile >= P.n_tiles)
             break;
-        freq_tile<SF>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
+        freq_tile<SF, EMIS>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
     }
     if (lds_iang) {
         __syncthreads();

@@ -181,7 +181,7 @@ struct rt_hip_plan {
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
 // the shipped inputs; 0 = any N)
-template <int SF>
+template <int SF, bool EMIS>
 static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
@@ -192,7 +192,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     // histogram; fewer than 4 rows is not worth having
     const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + rt::EXP_TAB * sizeof(double);
     const size_t lds_fix  = lds_stat + (in_lds ? ang_bytes : 0) + 1024;
-    const size_t lds_wg   = (size_t) (160 * 1024) / RT_FREQ_WAVES;
+    const size_t lds_wg   = (size_t) (160 * 1024) / (EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED);
     int nslot = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / ((size_t) 4 * (size_t) p->P.Kp * sizeof(double))) : 0;
     nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
     const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.Kp * sizeof(double);
@@ -209,7 +209,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         cap = cap_blocks;
     const unsigned grid = (unsigned) (want < cap ? want : cap);
     if (grid > 0) {
-        hipLaunchKernelGGL((rt::rt_freq_kernel<SF>), dim3(grid), dim3(256), lds, stream, p->P, in_lds, nslot);
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3(256), lds, stream, p->P, in_lds, nslot);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
@@ -286,7 +286,10 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     } else if (!(p->P.debug & 1u)) {
         const int S = p->P.L * RT_N_SUB;
         int rc;
-        rc = (S == 6) ? launch_freq<6>(p, stream, 0) : launch_freq<0>(p, stream, 0);
+        if (p->P.use_emis)
+            rc = (S == 6) ? launch_freq<6, true>(p, stream, 0) : launch_freq<0, true>(p, stream, 0);
+        else
+            rc = (S == 6) ? launch_freq<6, false>(p, stream, 0) : launch_freq<0, false>(p, stream, 0);
         if (rc != RT_OK)
             return rc;
     }
