@@ -162,6 +162,8 @@ struct rt_hip_plan {
     size_t path_rays   = 0;
     size_t rec_bytes   = 0;
     hipEvent_t evm     = nullptr; // between march and frequency kernels
+    hipStream_t helper = nullptr; // second queue for the co-resident march helper (plan_run_split)
+    hipEvent_t ev_go = nullptr, ev_helped = nullptr;
     double *image_own  = nullptr;
     double *iang_own   = nullptr;
     rt::DevCtl *ctl    = nullptr;
@@ -269,12 +271,35 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         p->P.path_err = p->path_err;
     }
     HIP_TRY(hipEventRecord(p->ev0, stream));
+    // Co-resident helper.  The LDS variant fills a CU with ONE 1024-thread work-group (the blob
+    // admits no second copy): 4 waves per SIMD at ~80 VGPRs, and the march is latency-bound
+    // there (dependent f32 chains, LDS round trips; ~55 % VALU issue).  The registers and wave
+    // slots left over take two 256-thread work-groups of the global-table variant per CU,
+    // launched on a second queue; they pull rays from the same counter, so the split balances
+    // itself.  Measured: -4 % (ASE stand-in) to -6 % on the march.  Opt-in
+    // (RT_HIP_MARCH_HELPER=<work-groups per CU>, 2 is best): under a serialising profiler the
+    // two launches no longer overlap and the per-kernel account stops matching the event times.
+    const char *hv      = getenv("RT_HIP_MARCH_HELPER");
+    const int helper_wg = (lds_tab && grid == cap && hv) ? atoi(hv) : 0;
     if (grid > 0) {
+        if (helper_wg > 0) {
+            HIP_TRY(hipEventRecord(p->ev_go, stream)); // after the memsets of this run
+            HIP_TRY(hipStreamWaitEvent(p->helper, p->ev_go, 0));
+        }
         if (lds_tab)
             hipLaunchKernelGGL(rt::rt_march_kernel<true>, dim3(grid), dim3(bthr), mlds, stream, p->P);
         else
             hipLaunchKernelGGL(rt::rt_march_kernel<false>, dim3(grid), dim3(bthr), mlds, stream, p->P);
         HIP_TRY(hipGetLastError());
+        if (helper_wg > 0) {
+            rt::DevParams Ph = p->P;
+            Ph.chunk         = 64; // the helper's waves are slower: small reservations keep the tail short
+            hipLaunchKernelGGL(rt::rt_march_kernel<false>, dim3((unsigned) p->cu_count * (unsigned) helper_wg), dim3(256), 0,
+                               p->helper, Ph);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(p->ev_helped, p->helper));
+            HIP_TRY(hipStreamWaitEvent(stream, p->ev_helped, 0));
+        }
     }
     HIP_TRY(hipEventRecord(p->evm, stream));
     if (p->path_on) {
@@ -341,6 +366,12 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         (void) hipEventDestroy(p->ev1);
     if (p->evm)
         (void) hipEventDestroy(p->evm);
+    if (p->ev_go)
+        (void) hipEventDestroy(p->ev_go);
+    if (p->ev_helped)
+        (void) hipEventDestroy(p->ev_helped);
+    if (p->helper)
+        (void) hipStreamDestroy(p->helper);
     pool_free(p->device, p->tan_dev);
     pool_free(p->device, p->rec);
     (void) hipFree(p->path_dev);
@@ -577,6 +608,9 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipEventCreate(&p->evm));
+    PLAN_TRY(hipEventCreateWithFlags(&p->ev_go, hipEventDisableTiming));
+    PLAN_TRY(hipEventCreateWithFlags(&p->ev_helped, hipEventDisableTiming));
+    PLAN_TRY(hipStreamCreateWithFlags(&p->helper, hipStreamNonBlocking));
     P.rec_stride = (unsigned) align_up((size_t) L * RT_N_SUB * 12 + sizeof(rt::RecMeta), 16);
     P.c_cap      = 0.5f * 1.00001f; // step safety factor c = 0.5 (Helper.h:381), see rt_hip_plan_set_step_factor
     P.c_h1       = 0.5f * 0.1f;
