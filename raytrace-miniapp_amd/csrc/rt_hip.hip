@@ -233,7 +233,9 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     // global variant when the blob does not fit (RT_HIP_MARCH=global forces it)
     const char *force   = getenv("RT_HIP_MARCH");
     const bool lds_tab  = p->P.blob_bytes <= 152 * 1024 && !(force && strcmp(force, "global") == 0);
-    const unsigned bthr = lds_tab ? 1024u : 256u;
+    unsigned bthr = lds_tab ? 1024u : 256u;
+    if (const char *e = getenv("RT_HIP_MARCH_THREADS")) // occupancy experiments
+        bthr = (unsigned) atoi(e);
     const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
     int per_cu          = 0;
     if (lds_tab) {

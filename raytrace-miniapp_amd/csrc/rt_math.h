@@ -115,10 +115,11 @@ __device__ __forceinline__ void renormalise(float &sx, float &sy, float &sz)
 // q = RN(a*y), r = a - b*q (exact with FMA), result RN(q + r*y) = RN(a/b)
 // (Markstein's correction step).  Checked against IEEE division on the CPU by
 // tests/test_float_identities.py (1e9 random pairs, and every float for the
-// constant divisors).  Two cases are routed away from the correction because it
-// is not exact there: a zero residual keeps q (preserves the sign of a zero
-// quotient), and dividends so small that the residual leaves the normal range
-// (|a| < 1e-29f, resp. 1e-280) take a true division -- unless the caller states
+// constant divisors).  The correction term is at most half an ulp of q, so the result has
+// the sign of q; copying it over preserves the sign of a zero quotient (-0 + +0 would give
+// +0), the one thing the correction gets wrong.  Dividends so small that the residual
+// leaves the normal range (|a| < 1e-29f, resp. 1e-280) take a true division -- unless the
+// caller states
 // that such a quotient cannot matter (TINY_OK):
 //   * float, TINY_OK: the quotient is added to 1.0f (ht/3, ht^2/12, ht^2/6 in the
 //     integrator step): below 2^-26 it is absorbed whatever its last bits are;
@@ -130,8 +131,7 @@ template <bool TINY_OK = false> __device__ __forceinline__ float div_by_recip(fl
 {
     const float q = a * y;
     const float r = fmaf(-b, q, a);
-    float c       = fmaf(r, y, q);
-    c             = (r == 0.0f) ? q : c;
+    float c       = copysignf(fmaf(r, y, q), q);
 #ifndef RT_ABL_NOGUARD
     if (!TINY_OK && fabsf(a) < 1e-29f && a != 0.0f) { // the residual must stay a normal float: |a| > 2^-102 (CPU test: none above 3e-32)
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
@@ -144,8 +144,7 @@ template <bool TINY_OK = false> __device__ __forceinline__ double div_by_recip(d
 {
     const double q = a * y;
     const double r = fma(-b, q, a);
-    double c       = fma(r, y, q);
-    c              = (r == 0.0) ? q : c;
+    double c       = copysign(fma(r, y, q), q);
 #ifndef RT_ABL_NOGUARD
     if (!TINY_OK && fabs(a) < 1e-280 && a != 0.0) { // residual normal: |a| > 2^-969
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch

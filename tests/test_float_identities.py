@@ -83,9 +83,9 @@ static inline float fb(uint32_t u){float f; memcpy(&f,&u,4); return f;}
 static inline uint32_t bf(float f){uint32_t u; memcpy(&u,&f,4); return u;}
 static inline uint64_t bd(double f){uint64_t u; memcpy(&u,&f,8); return u;}
 /* raytrace-miniapp_amd/csrc/rt_math.h, div_by_recip, restated for the host */
-static inline float d32(float a, float b, float y){ float q=a*y, r=fmaf(-b,q,a), c=fmaf(r,y,q); c=(r==0.0f)?q:c;
+static inline float d32(float a, float b, float y){ float q=a*y, r=fmaf(-b,q,a), c=copysignf(fmaf(r,y,q), q);
     if (fabsf(a) < 1e-29f && a != 0.0f) c = a/b; return c; }
-static inline double d64(double a, double b, double y){ double q=a*y, r=fma(-b,q,a), c=fma(r,y,q); c=(r==0.0)?q:c;
+static inline double d64(double a, double b, double y){ double q=a*y, r=fma(-b,q,a), c=copysign(fma(r,y,q), q);
     if (fabs(a) < 1e-280 && a != 0.0) c = a/b; return c; }
 static uint64_t s = 88172645463325252ULL;
 static inline uint64_t xr(void){ s^=s<<13; s^=s>>7; s^=s<<17; return s; }
