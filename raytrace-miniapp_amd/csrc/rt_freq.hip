@@ -198,6 +198,7 @@ __device__ __forceinline__ int deposit_index_fast(int n, const double *g, double
 // per-wave LDS scratch of the few-runs deposit: [4][XP_ROW] transposition rows (row stride
 // 66 doubles: 16-byte aligned, rows 4 banks apart) + [FREQ_MAXQ][64] window totals
 constexpr int XP_ROW          = 66;
+constexpr int XS_ROW          = 17; // exclusive mode: staging row of 16 frequencies + 1 (bank spread)
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
 
@@ -464,14 +465,30 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     };
 
     if (excl_all) {
-        // one ray per pixel: plain stores of the row, no reduction, no atomics
+        // One ray per pixel: plain stores of the row, no reduction, no atomics.  A lane owns a
+        // whole image row (K doubles), so lane-wise stores would put 32 bytes into each of 64 rows
+        // per instruction; instead the wave stages 16 frequencies of all its rows in LDS
+        // (cache = [64][XS_ROW] here) and stores them as 4 rows x 128 contiguous bytes per
+        // instruction.
         frequency_loop([&](int kb, double (&v)[VEC]) {
+            double *mine = cache + lane * XS_ROW + (kb & 12);
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-                if (own_pix >= 0 && kb + j < K)
-                    P.image[(size_t) own_pix * (size_t) K + (size_t) (kb + j)] = (pix == own_pix) ? v[j] : 0.0;
+                mine[j] = (pix == own_pix) ? v[j] : 0.0;
                 if (pix >= 0 && pix != own_pix && kb + j < K)
                     unsafeAtomicAdd(&img_row[kb + j], v[j]);
+            }
+            if ((kb & 12) == 12 || kb + VEC >= K) {
+                __builtin_amdgcn_wave_barrier();
+                const int k = (kb & ~15) + (lane & 15);
+#pragma unroll 4
+                for (int g = 0; g < WAVE / 4; g++) {
+                    const int row  = 4 * g + (lane >> 4);
+                    const int opix = __shfl(own_pix, row, WAVE);
+                    if (opix >= 0 && k < K)
+                        P.image[(size_t) opix * (size_t) K + (size_t) k] = cache[row * XS_ROW + (lane & 15)];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         });
     } else if (few) {
@@ -609,7 +626,8 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
     double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
     const int n_ang  = P.beam.na * P.beam.nb;
     double *cache_wg = reinterpret_cast<double *>(lds_raw) + (iang_in_lds ? n_ang : 0);
-    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (size_t) nslot * (size_t) P.Kp;
+    // per wave: the row cache [nslot][Kp], or in exclusive mode the store staging rows [64][XS_ROW]
+    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (P.exclusive ? (size_t) WAVE * XS_ROW : (size_t) nslot * (size_t) P.Kp);
     for (int c = (int) threadIdx.x; c < 4 * nslot * P.Kp; c += (int) blockDim.x)
         cache_wg[c] = 0.0;
     for (int c = (int) threadIdx.x; c < EXP_TAB; c += (int) blockDim.x)

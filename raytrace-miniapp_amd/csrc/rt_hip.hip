@@ -197,7 +197,11 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     const size_t lds_wg   = (size_t) (160 * 1024) / (EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED);
     int nslot = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / ((size_t) 4 * (size_t) p->P.Kp * sizeof(double))) : 0;
     nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
-    const size_t lds = (in_lds ? ang_bytes : 0) + (size_t) 4 * (size_t) nslot * (size_t) p->P.Kp * sizeof(double);
+    if (p->P.exclusive) // no reduction at all; the space holds the store staging rows instead
+        nslot = 0;
+    const size_t lds = (in_lds ? ang_bytes : 0) +
+                       (p->P.exclusive ? (size_t) 4 * rt::WAVE * rt::XS_ROW * sizeof(double)
+                                       : (size_t) 4 * (size_t) nslot * (size_t) p->P.Kp * sizeof(double));
     // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
     // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
     // (surplus work-groups find the tile counter exhausted and leave)
