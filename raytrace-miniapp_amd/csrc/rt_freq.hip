@@ -306,7 +306,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     // frequencies.  Otherwise (seeded mode: 4..8 pixels per tile): every distinct pixel owns one
     // row of the wave's LDS row cache [nslot][Kp]; lanes add into their pixel's row with LDS f64
     // atomics, rows are flushed per tile with coalesced atomics.  More distinct pixels than
-    // rows: a segmented shuffle scan over the runs.
+    // rows: a segmented shuffle scan over the runs (adding the lanes of the surplus pixels
+    // to the image one by one was tried: twice as slow on the 124.8 M-ray seeded case).
     constexpr int MAXQ               = FREQ_MAXQ;
     const int pix_before             = __shfl_up(pix, 1, WAVE);
     const unsigned long long head_m  = __ballot(lane == 0 || pix_before != pix);
@@ -549,7 +550,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         // lanes share a pixel add their values with two quad_perm DPP steps and send one atomic
         double *my_row       = cache + (size_t) (slot >= 0 ? slot : 0) * (size_t) Kp;
         const int slot_first = __builtin_amdgcn_update_dpp(0, slot, 0x00, 0xf, 0xf, true); // quad_perm:[0,0,0,0]
-        const unsigned long long same = __ballot(slot == slot_first);
+        const unsigned long long same = __ballot(slot == slot_first && slot >= 0);
         const bool quad_one  = ((same >> (lane & ~3)) & 0xfull) == 0xfull;
         const bool sender    = slot >= 0 && (!quad_one || (lane & 3) == 0);
         frequency_loop([&](int kb, double (&v)[VEC]) {

@@ -187,6 +187,7 @@ template <int SF, bool EMIS>
 static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
+    // (one global atomic per ray on na*nb addresses serialises badly: the histogram stays in LDS)
     const int in_lds       = ang_bytes <= 32 * 1024;
     // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K doubles,
     // sized so that the RT_FREQ_WAVES work-groups per CU the register budget allows still fit
@@ -194,8 +195,13 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     // histogram; fewer than 4 rows is not worth having
     const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + rt::EXP_TAB * sizeof(double);
     const size_t lds_fix  = lds_stat + (in_lds ? ang_bytes : 0) + 1024;
-    const size_t lds_wg   = (size_t) (160 * 1024) / (EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED);
-    int nslot = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / ((size_t) 4 * (size_t) p->P.Kp * sizeof(double))) : 0;
+    const size_t row_wg   = (size_t) 4 * (size_t) p->P.Kp * sizeof(double); // one cache row in each of the 4 waves
+    size_t lds_wg         = (size_t) (160 * 1024) / (EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED);
+    int nslot             = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / row_wg) : 0;
+    if (!EMIS && nslot < 7) { // seeded tiles hold ~7 pixels: rather one work-group less per CU than no row for them
+        lds_wg = (size_t) (160 * 1024) / (RT_FREQ_WAVES_SEED - 1);
+        nslot  = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / row_wg) : 0;
+    }
     nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
     if (p->P.exclusive) // no reduction at all; the space holds the store staging rows instead
         nslot = 0;
