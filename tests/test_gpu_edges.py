@@ -260,3 +260,30 @@ def test_small_and_odd_frequency_counts(hip, oracle, ase_small, nv):
     ref = oracle.image_loop(p, rays)
     assert out["failure_code"] == 0
     assert rel_l2(out["image"], ref["image"]) < TIGHT and rel_l2(out["I_ang"], ref["I_ang"]) < TIGHT
+
+
+def test_deposit_modes_of_the_seeded_pass(hip, oracle, seed_small):
+    """The three reductions behind the seeded deposit, each against the oracle:
+    (i) rays in random order -- equal pixels are not contiguous in a tile, many distinct pixels:
+        row cache keyed by distinct pixels, or the segmented scan when a tile has more than rows;
+    (ii) a frequency axis too long for cache rows in LDS (nv = 300): segmented scan only;
+    (iii) the grid-mode seed factor tables against the per-ray evaluation of the list path."""
+    rng = np.random.default_rng(7)
+    ids = np.sort(rng.permutation(seed_small.n_rays_total)[:60000]).astype(np.int64)
+    shuffled = rng.permutation(ids)
+    rays = seed_small.build_rays(shuffled)
+    out, ref = run_hip(hip, seed_small, rays), oracle.image_loop(seed_small, rays)
+    assert out["failure_code"] == ref["failure_code"] == 0
+    assert rel_l2(out["image"], ref["image"]) < 1e-11 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-11
+    wide = problem_mod.resample_frequency(seed_small, 300)
+    rays = wide.build_rays(ids[::3])
+    out, ref = run_hip(hip, wide, rays), oracle.image_loop(wide, rays)
+    assert rel_l2(out["image"], ref["image"]) < 1e-11 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-11
+    sub = copy.copy(seed_small)
+    sub.seed_beam = copy.copy(seed_small.seed_beam)
+    sub.seed_beam.x = seed_small.seed_beam.x[10:14].copy()     # 4 x 25 x 51 x 51 launch points and angles
+    grid = run_hip(hip, sub)
+    lst = run_hip(hip, sub, sub.build_rays())
+    ref = oracle.image_loop(sub, n_threads=4)
+    assert np.array_equal(grid["image"], lst["image"]) or rel_l2(grid["image"], lst["image"]) < 1e-13
+    assert rel_l2(grid["image"], ref["image"]) < 1e-11 and rel_l2(grid["I_ang"], ref["I_ang"]) < 1e-11
