@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     float px = 0, py = 0, pz = 0, sx = 0, sy = 0, sz = 1;
     float gacc = 0, eacc = 0;
     int cell_last = 0, n_done = 0;
+    BlobGain G    = hdr[1]; // header of the lane's current length ii, re-read only when ii changes
     unsigned steps = 0;
     bool escaped = false, any_nz = false, mirror = false;
     // cell (corner values are re-read from the blob in block [B])
@@ -325,6 +326,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 seg       = 0;
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
+                G         = hdr[ii];
                 z         = 0.0f;
                 z_stop    = zs0;
                 gacc      = 0.0f;
@@ -379,6 +381,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                         ++seg;
                         ii = backward ? P.N - seg - 1 : seg + 1;
                         z  = 0.0f;
+                        if (seg < L)
+                            G = hdr[ii];
                     }
                     if (seg == L) {
                         n_done = S;
@@ -392,7 +396,6 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             RT_MARK(1); // [A1]
             if ((st == ST_CELL) & in_seg) {
                 // [A2] escape test + cell setup (Helper.h:465-497)
-                const BlobGain G = hdr[ii];
                 // (double)(sz*sz) < 0.01 (Helper.h:466) <=> sz*sz <= 0.01f: 0.01f is the largest float below 0.01
                 if ((px < G.lo_x) | (px > G.hi_x) | (py < G.lo_y) | (py > G.hi_y) | (sz * sz <= 0.01f)) {
                     escaped = true; // its slot is committed by [A1] next iteration
