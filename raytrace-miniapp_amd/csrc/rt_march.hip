@@ -246,8 +246,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     BlobGain G    = hdr[1]; // header of the lane's current length ii, re-read only when ii changes
     unsigned steps = 0;
     bool escaped = false, any_nz = false, mirror = false;
-    // cell (corner values are re-read from the blob in block [B])
-    int c00 = 0, node_off = 0, row_bytes = 0; // corner node (index, blob byte offset), bytes per grid row
+    // cell
+    int c00 = 0;                              // index of the lower-left corner node of the current cell
+    double n00 = 1, n10 = 1, n01 = 1, n11 = 1; // refractive index at its four corners (gathered in [A2] with g0, E0)
     double xc0 = 0, yc0 = 0;  // lower-left corner coordinates of the current cell
     double rwx = 1, rwy = 1;  // 1/(double)wx, 1/(double)wy of the current cell
     float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
@@ -426,8 +427,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                         a01 = node[c00 + G.Nx];
                         a11 = node[c00 + G.Nx + 1];
                     }
-                    node_off  = G.off_node + c00 * (int) sizeof(Node);
-                    row_bytes = G.Nx * (int) sizeof(Node);
+                    n00       = a00.n;
+                    n10       = a10.n;
+                    n01       = a01.n;
+                    n11       = a11.n;
                     xc0       = X.lo;
                     yc0       = Y.lo;
                     rwx       = X.rw;
@@ -490,10 +493,6 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         RT_MARK(3); // DONE
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
-            const double n00 = *reinterpret_cast<const double *>(tab + node_off);
-            const double n10 = *reinterpret_cast<const double *>(tab + node_off + (int) sizeof(Node));
-            const double n01 = *reinterpret_cast<const double *>(tab + node_off + row_bytes);
-            const double n11 = *reinterpret_cast<const double *>(tab + node_off + row_bytes + (int) sizeof(Node));
             const float ya   = mirror ? fabsf(py) : py;
             const double dwx = (double) wx, dwy = (double) wy;
             const float u    = (float) div_by_recip<true>((double) px - xc0, dwx, rwx);
