@@ -244,6 +244,14 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     const char *force   = getenv("RT_HIP_MARCH");
     const bool lds_tab  = p->P.blob_bytes <= 152 * 1024 && !(force && strcmp(force, "global") == 0);
     unsigned bthr = lds_tab ? 1024u : 256u;
+    if (lds_tab) {
+        // Few rays per lane leave the persistent lanes waiting for the longest ray of a short
+        // queue: below about three rays per lane, fewer and busier lanes win (ASE_small, 399 000
+        // rays on 256 CUs: 0.65 ms with 1024 threads per CU, 0.44 ms with 512; 8 waves per CU is
+        // the least that still hides latency).
+        const unsigned long long per_cu_rays = p->cu_count ? p->n_rays / (unsigned long long) p->cu_count : 0;
+        bthr = per_cu_rays >= 3ull * 1024 ? 1024u : (per_cu_rays >= 3ull * 768 ? 768u : 512u);
+    }
     if (const char *e = getenv("RT_HIP_MARCH_THREADS")) // occupancy experiments
         bthr = (unsigned) atoi(e);
     const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;

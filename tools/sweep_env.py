@@ -7,7 +7,8 @@ be = importlib.import_module("raytrace-miniapp_amd.backend")
 var, vals = sys.argv[1], sys.argv[2:]
 case = os.environ.get("RT_CASE", "ase")
 base = rt.datfile.load('tests/golden/ASE_small.dat.xz')
-p = rt.scale_problem(base, 16.0) if case == "ase" else rt.datfile.load('tests/golden/seed_small.dat.xz')
+p = {"ase": lambda: rt.scale_problem(base, 16.0), "small": lambda: base,
+     "seed": lambda: rt.datfile.load('tests/golden/seed_small.dat.xz')}[case]()
 best = {v: (1e9, 1e9) for v in vals}
 with be.Plan(p) as plan:
     plan.set_ray_grid()
