@@ -303,6 +303,11 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     const int helper_wg = (lds_tab && grid == cap && hv) ? atoi(hv) : 0;
     if (grid > 0) {
         if (helper_wg > 0) {
+            if (!p->helper) { // created on first use: a queue costs about a millisecond
+                HIP_TRY(hipEventCreateWithFlags(&p->ev_go, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&p->ev_helped, hipEventDisableTiming));
+                HIP_TRY(hipStreamCreateWithFlags(&p->helper, hipStreamNonBlocking));
+            }
             HIP_TRY(hipEventRecord(p->ev_go, stream)); // after the memsets of this run
             HIP_TRY(hipStreamWaitEvent(p->helper, p->ev_go, 0));
         }
@@ -628,9 +633,6 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipEventCreate(&p->evm));
-    PLAN_TRY(hipEventCreateWithFlags(&p->ev_go, hipEventDisableTiming));
-    PLAN_TRY(hipEventCreateWithFlags(&p->ev_helped, hipEventDisableTiming));
-    PLAN_TRY(hipStreamCreateWithFlags(&p->helper, hipStreamNonBlocking));
     P.rec_stride = (unsigned) align_up((size_t) L * RT_N_SUB * 12 + sizeof(rt::RecMeta), 16);
     P.c_cap      = 0.5f * 1.00001f; // step safety factor c = 0.5 (Helper.h:381), see rt_hip_plan_set_step_factor
     P.c_h1       = 0.5f * 0.1f;
