@@ -9,12 +9,12 @@
 # gpurun_out/prof_<tag>/ ; summarise with profiles/summarize.py.
 set -e -o pipefail
 TAG=${1:-r01}
-STEPS=${2:-5}
+STEPS=${2:-20}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+CMD="python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/bench_trace.log" 2>&1
 echo "trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $CMD > "$OUT/bench_fetch.log" 2>&1
