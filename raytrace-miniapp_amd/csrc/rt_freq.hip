@@ -337,6 +337,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     float gs[SF ? SF : 1];
     double rs[SF ? SF : 1]; // es/gs, the source function of the sub-segment (see ase_step)
     int cs[SF ? SF : 1];
+    bool irregular = false;
     if (SF) {
 #pragma unroll
         for (int s = 0; s < SF; s++) {
@@ -345,10 +346,16 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             const float e1   = sl.e;
             cs[s]            = sl.c;
             rs[s]          = fabsf(gs[s]) >= RT_RS_MIN ? div_fast((double) e1, (double) gs[s]) : 0.0;
+            // a sub-segment the source-function form cannot take: gain sum tiny or NaN, but not the
+            // identity (both sums zero -- which ase_step reproduces: x = 0, e^x - 1 = 0)
+            irregular = irregular || (!(fabsf(gs[s]) >= RT_RS_MIN) && (gs[s] != 0.0f || e1 != 0.0f));
             if (use_emis && fabsf(gs[s]) >= RT_RS_MIN)
                 gs[s] = __builtin_amdgcn_fmed3f(gs[s], -P.gs_cap, P.gs_cap); // keeps |gs * gv| <= 708
         }
     }
+    // no such sub-segment in the whole tile (the rule): the six updates of a frequency batch run
+    // as one straight-line block, so the table reads of one overlap the arithmetic of another
+    const bool all_regular = __ballot(irregular) == 0ull;
 
     double angsum = 0.0; // RayTraceImageCPU.cpp:63-68, sequential in k like the CPU
     double iv_min = 0.0; // min over k of Iv, NaNs ignored: negative <=> error -2 (Helper.h:582-594)
@@ -383,6 +390,14 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
                             wnan[j] = wnan[j] || w[s].v[j] != w[s].v[j];
+                    }
+                    if (all_regular) {
+#pragma unroll
+                        for (int s = 0; s < SF; s++)
+                            ase_step(Iv, gs[s], rs[s], w[s].v, tab);
+                    } else
+#pragma unroll
+                    for (int s = 0; s < SF; s++) {
                         if (fabsf(gs[s]) >= RT_RS_MIN) {
                             ase_step(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
