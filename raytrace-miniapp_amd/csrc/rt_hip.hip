@@ -273,6 +273,8 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
     ch                    = ch < 16 ? 16 : (ch > 512 ? 512 : ch);
     p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
+    if (const char *e = getenv("RT_HIP_MARCH_CHUNK")) // tuning
+        p->P.chunk = (unsigned) atoi(e);
     p->P.path_on = p->path_on ? 1u : 0u;
     if (p->path_on) {
         const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
