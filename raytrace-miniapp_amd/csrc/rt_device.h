@@ -40,8 +40,8 @@ struct alignas(16) BlobGain {
     float lo_x, hi_x, lo_y, hi_y; // plasma box as floats (Helper.h:445-453), lo_y = -hi_y if mirrored
     int Nx, Ny, mirror_y, off_ix;
     int off_iy, off_node, pad0, pad1;
-    double x0, y0;                // x[0], y[0]
-    double inv_hx, inv_hy;        // (Nx-1)/(x[Nx-1]-x[0]): index guess on uniform grids
+    float x0f, y0f;               // x[0], y[0]
+    float inv_hxf, inv_hyf;       // (Nx-1)/(x[Nx-1]-x[0]): index guess on uniform grids
 };
 
 // One grid interval (g[u-1], g[u]] of one axis, u = 1 .. n-1 (entry 0 unused): everything a

@@ -521,14 +521,12 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         }
         h.Nx     = g.Nx;
         h.Ny     = g.Ny;
-        h.x0     = g.x[0];
-        h.y0     = g.y[0];
-        h.inv_hx = (double) (g.Nx - 1) / (g.x[g.Nx - 1] - g.x[0]);
-        h.inv_hy = (double) (g.Ny - 1) / (g.y[g.Ny - 1] - g.y[0]);
-        if (!std::isfinite(h.inv_hx))
-            h.inv_hx = 0.0;
-        if (!std::isfinite(h.inv_hy))
-            h.inv_hy = 0.0;
+        h.x0f = (float) g.x[0];
+        h.y0f = (float) g.y[0];
+        const double ihx = (double) (g.Nx - 1) / (g.x[g.Nx - 1] - g.x[0]);
+        const double ihy = (double) (g.Ny - 1) / (g.y[g.Ny - 1] - g.y[0]);
+        h.inv_hxf        = std::isfinite(ihx) && fabs(ihx) < 1e30 ? (float) ihx : 0.0f;
+        h.inv_hyf        = std::isfinite(ihy) && fabs(ihy) < 1e30 ? (float) ihy : 0.0f;
         // per-interval records of both axes (entry 0 unused)
         auto put_intervals = [&](const double *gp, int n, bool mirrored) {
             const int off = (int) blob.size();

@@ -190,8 +190,9 @@ __device__ __forceinline__ int bisect_interval(const Interval *iv, int n, double
     }
     return hi;
 }
-__device__ __forceinline__ int guess_interval(int n, double g0, double inv_h, double v)
+__device__ __forceinline__ int guess_interval(int n, float g0, float inv_h, float v)
 {
+    // a guess only (the caller verifies it against the interval's own coordinates): float is enough
     const int last = n - 1;
     int u          = (int) ((v - g0) * inv_h) + 1;
     return u < 1 ? 1 : (u > last ? last : u);
@@ -408,8 +409,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     const float ya      = mirror ? fabsf(py) : py;
                     const double pxd = (double) px, yad = (double) ya;
                     // one round of gathers on the guessed cell: two interval records, four nodes
-                    int k1     = guess_interval(G.Nx, G.x0, G.inv_hx, pxd);
-                    int k2     = guess_interval(G.Ny, G.y0, G.inv_hy, yad);
+                    int k1     = guess_interval(G.Nx, G.x0f, G.inv_hxf, px);
+                    int k2     = guess_interval(G.Ny, G.y0f, G.inv_hyf, ya);
                     Interval X = ivx[k1], Y = ivy[k2];
                     c00        = (k1 - 1) + (k2 - 1) * G.Nx;
                     Node a00 = node[c00], a10 = node[c00 + 1];
@@ -453,7 +454,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     zc    = 0.0f;
                     path  = 0.0f;
                     dzrem = z_stop - z;
-                    if ((px > b0) & (px < b1) & (ya > b2) & (ya < b3) & ((double) zc < 0.999 * (double) dzrem)) {
+                    // Helper.h:327 with zc = 0: 0.0 < 0.999 * (double) dzrem <=> dzrem > 0 (no underflow in double)
+                    if ((px > b0) & (px < b1) & (ya > b2) & (ya < b3) & (dzrem > 0.0f)) {
                         st = ST_XSETUP;
                     } else {
                         // no cross-cell iteration at all: the cell step still counts (Helper.h:498-503)
