@@ -109,7 +109,7 @@ struct RecMeta {
 
 // Zeroed by a memset node before every run.
 struct DevCtl {
-    unsigned int next_tile;   // march kernel: next unreserved ray index
+    unsigned int next_tile[8]; // march kernel: next unreserved ray, relative to ray_begin, per launch of a run
     unsigned int next_tile_b; // frequency kernel: next tile
     unsigned int failure_code;
     unsigned int n_failed;
@@ -146,6 +146,9 @@ struct DevParams {
     DevCtl *ctl;
     DevProbe probe;
     unsigned int n_tiles;
+    // march launch: rays [ray_begin, ray_end) of the list / grid, ray counter next_tile[launch_id]
+    // (a run is one launch, or several when the ray list is still arriving from the host)
+    unsigned int ray_begin, ray_end, launch_id, pad_launch;
     unsigned int debug; // bit0: skip the frequency kernel (profiling only, RT_HIP_DEBUG env)
     // rt_march.hip -> records -> rt_freq.hip
     const unsigned char *blob; // march blob (global copy)

@@ -162,8 +162,7 @@ struct rt_hip_plan {
     size_t path_rays   = 0;
     size_t rec_bytes   = 0;
     hipEvent_t evm     = nullptr; // between march and frequency kernels
-    hipStream_t helper = nullptr; // second queue for the co-resident march helper (plan_run_split)
-    hipEvent_t ev_go = nullptr, ev_helped = nullptr;
+    const rt_ray *host_rays = nullptr; // ray list still on the host, uploaded by the next run (rt_hip_image_loop)
     double *image_own  = nullptr;
     double *iang_own   = nullptr;
     rt::DevCtl *ctl    = nullptr;
@@ -225,6 +224,22 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
+}
+
+// One non-blocking queue per device for rt_hip_image_loop, kept across calls like the memory
+// pool (a resource, not data): synchronous copies on the host thread do not wait for it, which
+// is what lets the ray upload overlap the march.  Creating a queue costs ~2 ms: once.
+static hipStream_t loop_queue(int device)
+{
+    static std::mutex mu;
+    static hipStream_t q[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64)
+        return nullptr;
+    if (!q[device] && hipSetDevice(device) == hipSuccess &&
+        hipStreamCreateWithFlags(&q[device], hipStreamNonBlocking) != hipSuccess)
+        q[device] = nullptr;
+    return q[device];
 }
 
 // Two-kernel path: march (persistent lanes) -> records in HBM -> frequency pass.
@@ -293,41 +308,39 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         p->P.path_err = p->path_err;
     }
     HIP_TRY(hipEventRecord(p->ev0, stream));
-    // Co-resident helper.  The LDS variant fills a CU with ONE 1024-thread work-group (the blob
-    // admits no second copy): 4 waves per SIMD at ~80 VGPRs, and the march is latency-bound
-    // there (dependent f32 chains, LDS round trips; ~55 % VALU issue).  The registers and wave
-    // slots left over take two 256-thread work-groups of the global-table variant per CU,
-    // launched on a second queue; they pull rays from the same counter, so the split balances
-    // itself.  Measured: -4 % (ASE stand-in) to -6 % on the march.  Opt-in
-    // (RT_HIP_MARCH_HELPER=<work-groups per CU>, 2 is best): under a serialising profiler the
-    // two launches no longer overlap and the per-kernel account stops matching the event times.
-    const char *hv      = getenv("RT_HIP_MARCH_HELPER");
-    const int helper_wg = (lds_tab && grid == cap && hv) ? atoi(hv) : 0;
-    if (grid > 0) {
-        if (helper_wg > 0) {
-            if (!p->helper) { // created on first use: a queue costs about a millisecond
-                HIP_TRY(hipEventCreateWithFlags(&p->ev_go, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&p->ev_helped, hipEventDisableTiming));
-                HIP_TRY(hipStreamCreateWithFlags(&p->helper, hipStreamNonBlocking));
-            }
-            HIP_TRY(hipEventRecord(p->ev_go, stream)); // after the memsets of this run
-            HIP_TRY(hipStreamWaitEvent(p->helper, p->ev_go, 0));
+    // A run is one march launch -- or three, when the ray list is still on the host
+    // (rt_hip_image_loop): the list crosses PCIe in slices, each with a synchronous copy (the fast
+    // pageable path, ~35 GB/s; asynchronous copies of pageable memory reach a third of that), and
+    // the march of a slice runs on image_loop's non-blocking queue while the host copies the next
+    // one (16 B/ray: 102 MB, ~3 ms for the 6.4 M-ray case; swept: 3 slices 5.8 ms, 1 slice 6.9, 8 slices 7.3).
+    unsigned n_launch = (p->host_rays && p->n_rays >= (2ull << 20)) ? 3u : 1u;
+    if (const char *e = getenv("RT_HIP_UPLOAD_SLICES")) // tuning
+        n_launch = p->host_rays ? (unsigned) atoi(e) : 1u;
+    n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
+    for (unsigned c = 0; c < n_launch && grid > 0; c++) {
+        const unsigned long long b = p->n_rays * c / n_launch, e = p->n_rays * (c + 1) / n_launch;
+        if (p->host_rays) {
+            HIP_TRY(hipMemcpy(p->rays_dev + b, p->host_rays + b, (size_t) (e - b) * sizeof(rt_ray), hipMemcpyHostToDevice));
+            // Helper.h:409-410 for every ray of the slice, at full lane occupancy, before its march
+            hipLaunchKernelGGL(rt::rt_tan_kernel, dim3((unsigned) ((e - b + 255) / 256)), dim3(256), 0, stream, p->rays_dev + b,
+                               (unsigned long long) (e - b), p->tan_dev + 2 * b);
+            HIP_TRY(hipGetLastError());
         }
+        if (n_launch > 1) { // rays reserved per counter fetch, for this slice
+            unsigned long long cs = (e - b) / ((unsigned long long) grid * (bthr / 64) * 8);
+            cs                    = cs < 16 ? 16 : (cs > 512 ? 512 : cs);
+            p->P.chunk            = (unsigned) ((cs + 15) / 16 * 16);
+        }
+        p->P.ray_begin = (unsigned) b;
+        p->P.ray_end   = (unsigned) e;
+        p->P.launch_id = c;
         if (lds_tab)
             hipLaunchKernelGGL(rt::rt_march_kernel<true>, dim3(grid), dim3(bthr), mlds, stream, p->P);
         else
             hipLaunchKernelGGL(rt::rt_march_kernel<false>, dim3(grid), dim3(bthr), mlds, stream, p->P);
         HIP_TRY(hipGetLastError());
-        if (helper_wg > 0) {
-            rt::DevParams Ph = p->P;
-            Ph.chunk         = 64; // the helper's waves are slower: small reservations keep the tail short
-            hipLaunchKernelGGL(rt::rt_march_kernel<false>, dim3((unsigned) p->cu_count * (unsigned) helper_wg), dim3(256), 0,
-                               p->helper, Ph);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(p->ev_helped, p->helper));
-            HIP_TRY(hipStreamWaitEvent(stream, p->ev_helped, 0));
-        }
     }
+    p->host_rays = nullptr; // consumed: the list is on the device now
     HIP_TRY(hipEventRecord(p->evm, stream));
     if (p->path_on) {
         // the tracer replaces the frequency / deposit kernel: no image is produced
@@ -393,12 +406,6 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         (void) hipEventDestroy(p->ev1);
     if (p->evm)
         (void) hipEventDestroy(p->evm);
-    if (p->ev_go)
-        (void) hipEventDestroy(p->ev_go);
-    if (p->ev_helped)
-        (void) hipEventDestroy(p->ev_helped);
-    if (p->helper)
-        (void) hipStreamDestroy(p->helper);
     pool_free(p->device, p->tan_dev);
     pool_free(p->device, p->rec);
     (void) hipFree(p->path_dev);
@@ -657,6 +664,29 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     return RT_OK;
 }
 
+// rt_hip_image_loop only: the list stays on the host until the run, which uploads it in slices
+// beside the march (the caller's buffer outlives the call, the plan does not)
+static int plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
+{
+    HIP_TRY(hipSetDevice(p->device));
+    pool_free(p->device, p->rays_dev);
+    pool_free(p->device, p->tan_dev);
+    p->rays_dev = nullptr;
+    p->tan_dev  = nullptr;
+    if (n_rays) {
+        HIP_TRY(pool_alloc(p->device, (void **) &p->rays_dev, n_rays * sizeof(rt_ray)));
+        HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, n_rays * 2 * sizeof(float)));
+    }
+    p->P.exclusive  = 0;
+    p->P.rays       = {};
+    p->P.rays.list  = p->rays_dev;
+    p->P.rays.sxy   = p->tan_dev;
+    p->P.rays.count = n_rays;
+    p->n_rays       = n_rays;
+    p->host_rays    = n_rays ? rays : nullptr;
+    return RT_OK;
+}
+
 int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
 {
     if (!p || (n_rays && !rays))
@@ -685,6 +715,7 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
     p->P.rays.sxy   = p->tan_dev;
     p->P.rays.count = n_rays;
     p->n_rays       = n_rays;
+    p->host_rays    = nullptr;
     return RT_OK;
 }
 
@@ -723,6 +754,7 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     p->tan_dev = nullptr;
     HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, ht.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(p->tan_dev, ht.data(), ht.size() * sizeof(float), hipMemcpyHostToDevice));
+    p->host_rays   = nullptr;
     rt::DevRays &R = p->P.rays;
     R              = {};
     R.list         = nullptr;
@@ -1024,9 +1056,12 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
     int rc         = rt_hip_plan_create(&p, device, N, beam, gain, seed, method, scale);
     if (rc != RT_OK)
         return rc;
-    rc = rt_hip_plan_set_rays(p, rays, n_rays);
+    if (!rays && n_rays)
+        rc = fail_arg("rt_hip_image_loop: NULL ray list");
+    else
+        rc = plan_set_rays_deferred(p, rays, n_rays);
     if (rc == RT_OK)
-        rc = rt_hip_plan_run(p, nullptr, nullptr, nullptr);
+        rc = rt_hip_plan_run(p, loop_queue(device), nullptr, nullptr);
     if (rc == RT_OK)
         rc = rt_hip_plan_fetch(p, image, I_ang, failure_code, failed_rays, max_failed, n_failed, stats);
     rt_hip_plan_destroy(p);

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     const int lane        = lane_id();
     const int L           = P.L;
     const int S           = L * RT_N_SUB;
-    const unsigned n_rays = (unsigned) P.rays.count;
+    const unsigned n_rays = P.ray_end; // this launch marches rays [P.ray_begin, P.ray_end)
     const bool backward   = P.method == 1;
     const bool use_emis   = P.use_emis != 0;
     const unsigned CH     = P.chunk;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 if (chunk_next == chunk_end) {
                     unsigned base = 0;
                     if (lane == 0)
-                        base = atomicAdd(&P.ctl->next_tile, CH);
+                        base = P.ray_begin + atomicAdd(&P.ctl->next_tile[P.launch_id], CH);
                     base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
                     if (base >= n_rays) {
                         more = false;
