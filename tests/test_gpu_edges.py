@@ -287,3 +287,20 @@ def test_deposit_modes_of_the_seeded_pass(hip, oracle, seed_small):
     ref = oracle.image_loop(sub, n_threads=4)
     assert np.array_equal(grid["image"], lst["image"]) or rel_l2(grid["image"], lst["image"]) < 1e-13
     assert rel_l2(grid["image"], ref["image"]) < 1e-11 and rel_l2(grid["I_ang"], ref["I_ang"]) < 1e-11
+
+
+def test_sliced_ray_upload_of_the_host_pointer_entry(hip, oracle, ase_small, monkeypatch):
+    """rt_hip_image_loop uploads a long ray list in slices beside the march (one march launch per
+    slice, own ray counter each); forced here on a short list, ragged slice sizes included."""
+    ids = np.arange(5, ase_small.n_rays_total, 7, dtype=np.int64)[:50001]
+    rays = ase_small.build_rays(ids)
+    monkeypatch.setenv("RT_HIP_UPLOAD_SLICES", "1")
+    whole = hip.image_loop(ase_small, rays)
+    for n in ("2", "3", "7"):
+        monkeypatch.setenv("RT_HIP_UPLOAD_SLICES", n)
+        out = hip.image_loop(ase_small, rays)
+        assert out["stats"]["n_rays"] == len(rays) and out["stats"]["cell_steps"] == whole["stats"]["cell_steps"]
+        assert rel_l2(out["image"], whole["image"]) < 1e-13 and rel_l2(out["I_ang"], whole["I_ang"]) < 1e-13
+    ref = oracle.image_loop(ase_small, rays)
+    assert whole["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    assert rel_l2(whole["image"], ref["image"]) < TIGHT
