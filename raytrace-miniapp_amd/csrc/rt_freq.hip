@@ -13,9 +13,11 @@
 //           into the work-group's private I_ang, flushed once per work-group with
 //           coalesced native f64 atomics.
 //   image : consecutive rays hit the same pixel (ASE: all na*nb rays of a pixel;
-//           seeded: runs of neighbouring source angles), so the per-pixel sum over
-//           rays is a segmented wave scan over runs of equal pixel index (shuffles,
-//           masks built once per tile) and one atomic per run and frequency.
+//           seeded: a handful of pixels per tile), so most of the per-pixel sum over
+//           rays happens inside the wave -- one of four deposit modes per tile (few
+//           runs: LDS-transposed wave sums; several pixels: per-wave LDS row cache;
+//           one ray per pixel: staged plain stores; otherwise a segmented scan), each
+//           ending in coalesced f64 atomics or stores.  See freq_tile.
 #include "rt_march.hip"
 
 namespace rt {
@@ -24,7 +26,7 @@ namespace rt {
 #define RT_FREQ_WAVES_SEED 4 // the gain-only instance keeps far less per-lane state
 #endif
 #ifndef RT_FREQ_WAVES
-#define RT_FREQ_WAVES 3 // waves per SIMD the frequency kernel is compiled for (<= 168 VGPRs; 4 spills)
+#define RT_FREQ_WAVES 3 // waves per SIMD of the emission instance (<= 168 VGPRs; at 4, i.e. 128, it spills)
 #endif
 
 constexpr int VEC = 4; // frequencies per lane and pass; rows are padded to a multiple (DevParams::Kp)
@@ -33,8 +35,9 @@ struct alignas(16) FVec { float v[VEC]; };
 // ---- float64 building blocks of the frequency pass ---------------------------------
 // The frequency pass is the float64 half of the path; its results are compared with
 // the CPU loop under the 1e-5 rel-L2 gate, not bit for bit (different libm exp,
-// different summation order of the deposit).  Inside that contract the two costly
-// IEEE operations are replaced by 1-2 ulp equivalents and FMA contraction is allowed.
+// different summation order of the deposit, the source-function form of the update
+// below).  Inside that contract exp and division are 1-2 ulp table / Newton kernels and
+// FMA contraction is allowed.
 #pragma clang fp contract(fast)
 
 // exp(x), <= 2 ulp: x = (256 m + j) ln2/256 + r, |r| <= ln2/512;
