@@ -5,7 +5,8 @@
 // issue ~30 cudaMalloc/cudaMemcpy calls per create_image, a plan packs every
 // table into ONE arena, uploads it with ONE copy, zeroes outputs + control block
 // and launches the march kernel and the frequency kernel back to back on one
-// stream.  Nothing is cached across calls (Readme.txt:43).
+// stream.  No data is cached across calls (Readme.txt:43); freed device allocations and one
+// queue per device are (the pool and loop_queue below).
 #include "rt_path.hip" // debug path tracer (before rt_freq.hip: no FMA contraction there)
 #include "rt_freq.hip" // kernel B (includes rt_march.hip, kernel A)
 

@@ -13,10 +13,10 @@
 //     [A] cell-loop bookkeeping + cell setup, [B] cross-cell setup, [C] one
 //     integrator step, with the loop-exit tests evaluated eagerly at the end of
 //     [C] so that every live lane performs exactly one integrator step per
-//     iteration (93 % occupancy of the integrator step, measured).  The arithmetic
+//     iteration (92 % occupancy of the integrator step, measured).  The arithmetic
 //     and its order are exactly those of the nested loops: the march record is
 //     bit-identical to the CPU loop.
-// Tables: what a cell-step gathers -- grid coordinates and the fused
+// Tables: what a cell-step gathers -- per-axis interval records and the fused
 // {n, g0, E0} corner nodes of every length -- is one "march blob" (rt_device.h)
 // that each work-group copies into LDS once (LDS variant, one work-group per CU)
 // so that the dependent index -> coordinate -> corner read chain of block [A] costs
