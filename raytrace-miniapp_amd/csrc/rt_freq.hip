@@ -445,7 +445,11 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                 for (int s = 0; s < S; s++) {
                     const float g1    = SF ? gs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).g;
                     const int c1      = SF ? cs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).c;
+#ifdef RT_ABL_NOLOAD
+                    const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) (c1 & 1) * (size_t) Kp + kb;
+#else
                     const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
+#endif
                     const FVec w = *reinterpret_cast<const FVec *>(row);
 #pragma unroll
                     for (int j = 0; j < VEC; j++)
