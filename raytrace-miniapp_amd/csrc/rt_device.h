@@ -72,6 +72,7 @@ struct DevBeam {
     int nx, ny, na, nb, nv;
     int pad;
     double dx, dy, da, db;
+    double inv_dx, inv_dy, inv_da, inv_db; // 1/d, for the deposit-cell guess (verified against the grid)
 };
 
 struct DevRays {

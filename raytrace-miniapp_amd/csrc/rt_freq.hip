@@ -177,7 +177,7 @@ __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, cons
 // uniform-grid shortcut of deposit_index (RayTraceImageCPU.cpp:11-16): the grids
 // of the beam are uniform (create_image checks it); guess the cell arithmetically,
 // verify the two defining inequalities of findfirstsingle, else bisect.
-__device__ __forceinline__ int deposit_index_fast(int n, const double *g, double d, double v)
+__device__ __forceinline__ int deposit_index_fast(int n, const double *g, double d, double inv_d, double v)
 {
     const double g0 = g[0], gl = g[n - 1];
     if (v < g0 - 0.5 * d || v > gl + 0.5 * d)
@@ -189,7 +189,7 @@ __device__ __forceinline__ int deposit_index_fast(int n, const double *g, double
         return n;
     if (n < 2)
         return n;
-    int u = (int) ((t - g0) / d) + 1;
+    int u = (int) ((t - g0) * inv_d) + 1; // a guess: the two inequalities below decide
     u     = u < 1 ? 1 : (u > n - 1 ? n - 1 : u);
     // first_not_below on [g0, gl]: unique u in [1, n-1] with g[u-1] < t <= g[u]
     // (u = 1 also when t == g0, where the bisection never tests g[0])
@@ -267,10 +267,10 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         }
         if (P.probe_on)
             P.probe.ray2[ridx] = r2;
-        const int i1 = deposit_index_fast(P.beam.nx, P.beam.x, P.beam.dx, (double) out.x);
-        const int i2 = deposit_index_fast(P.beam.ny, P.beam.y, P.beam.dy, (double) out.y);
-        const int i3 = deposit_index_fast(P.beam.na, P.beam.a, P.beam.da, (double) out.a);
-        const int i4 = deposit_index_fast(P.beam.nb, P.beam.b, P.beam.db, (double) out.b);
+        const int i1 = deposit_index_fast(P.beam.nx, P.beam.x, P.beam.dx, P.beam.inv_dx, (double) out.x);
+        const int i2 = deposit_index_fast(P.beam.ny, P.beam.y, P.beam.dy, P.beam.inv_dy, (double) out.y);
+        const int i3 = deposit_index_fast(P.beam.na, P.beam.a, P.beam.da, P.beam.inv_da, (double) out.a);
+        const int i4 = deposit_index_fast(P.beam.nb, P.beam.b, P.beam.db, P.beam.inv_db, (double) out.b);
         if (i1 >= 0 && i2 >= 0)
             pix = i1 + i2 * P.beam.nx;
         if (i3 >= 0 && i4 >= 0)

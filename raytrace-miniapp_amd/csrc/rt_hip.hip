@@ -617,6 +617,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     P.beam.dy  = beam->dy;
     P.beam.da  = beam->da;
     P.beam.db  = beam->db;
+    P.beam.inv_dx = 1.0 / beam->dx;
+    P.beam.inv_dy = 1.0 / beam->dy;
+    P.beam.inv_da = 1.0 / beam->da;
+    P.beam.inv_db = 1.0 / beam->db;
     if (seed) {
         for (int i = 0; i < 5; i++) {
             P.seed.x[i]   = reinterpret_cast<const double *>(A + off_sx[i]);
