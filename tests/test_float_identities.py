@@ -211,3 +211,47 @@ def test_float_thresholds_equal_the_double_comparisons():
         got = op(x, as_float)
         assert np.array_equal(want, got)
     assert float(np.float32(0.05)) > 0.05 and float(np.float32(0.01)) < 0.01
+
+
+def test_source_function_form_of_the_ase_update_stays_within_its_bound():
+    """rt_freq.hip ase_step, restated in numpy, against the CPU formula (Helper.h:549-557) over
+    the range of the shipped tables and far beyond: six chained updates per sample, as a ray
+    sees them.  Bounds: the expm1 construction alone (same ratio on both sides) 1e-9; with the
+    per-sub-segment ratio es/gs, one float rounding per term, 2e-7."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    n = 200_000
+    tab = np.exp2(np.arange(256) / 256.0)
+    L2E, LN2_N, MAGIC = 369.3299304675746, 0.0027076061740622863, float.fromhex("0x1.8p52")
+
+    def em1_kernel(x):                      # e^x - 1 as the kernel builds it
+        t = x * L2E + MAGIC
+        nn = (t - MAGIC).astype(np.int64)
+        r = x - (t - MAGIC) * LN2_N
+        q = 1.0 + r * (0.5 + r / 6.0)
+        S = np.ldexp(tab[nn & 255], (nn >> 8).astype(np.int32))
+        return S * (r * q) + (S - 1.0)
+
+    def cpu_update(Iv, gl, el):             # Helper.h:551-557
+        small = np.abs(gl) < 1e-3
+        with np.errstate(divide="ignore", invalid="ignore"):
+            big = el / gl * (np.exp(gl) - 1.0) + Iv * np.exp(gl)
+        return np.where(small, el * (1.0 + 0.5 * gl * (1.0 + 0.3333333333 * gl)) + Iv * (1.0 + gl * (1.0 + 0.5 * gl)), big)
+
+    Iv_cpu = np.zeros(n)
+    Iv_same = np.zeros(n)                   # kernel expm1, CPU ratio el/gl
+    Iv_gpu = np.zeros(n)                    # kernel expm1, ratio es/gs
+    for s in range(6):
+        gs = (rng.uniform(-3.0, 3.0, n) * 10.0 ** rng.uniform(-6, 0, n)).astype(np.float32)
+        es = (np.abs(gs) * 10.0 ** rng.uniform(-6, -2, n)).astype(np.float32)
+        w = rng.uniform(0.002, 1.0, n).astype(np.float32)
+        gl = (gs * w).astype(np.float64)    # float32 product, then widened
+        el = (es * w).astype(np.float64)
+        Iv_cpu = cpu_update(Iv_cpu, gl, el)
+        em1 = em1_kernel(gl)
+        Iv_same = Iv_same + em1 * (Iv_same + el / gl)
+        Iv_gpu = Iv_gpu + em1 * (Iv_gpu + es.astype(np.float64) / gs.astype(np.float64))
+    scale = np.abs(Iv_cpu) + 1e-300
+    assert np.max(np.abs(Iv_same - Iv_cpu) / scale) < 1e-9
+    assert np.max(np.abs(Iv_gpu - Iv_cpu) / scale) < 2e-7
+    assert np.linalg.norm(Iv_gpu - Iv_cpu) / np.linalg.norm(Iv_cpu) < 5e-8
