@@ -180,6 +180,14 @@ int rt_hip_plan_enable_probe(rt_hip_plan *plan, int on);
 int rt_hip_plan_fetch_probe(rt_hip_plan *plan, float *gvl, float *evl, int32_t *ivl,
                             rt_ray *ray2, uint32_t *flags, uint32_t *steps);
 
+/* Emission (ASE) mode only.  By default the frequency pass advances
+ *   Iv' = Iv + (e^gl - 1)(Iv + evl/gvl)
+ * with the ratio taken once per sub-segment; the CPU (Helper.h:549-557) divides the two float32
+ * products el/gl per frequency, which differs by one float rounding per term: image and I_ang agree
+ * with RayTraceImageCPULoop to ~1e-8 rel-L2.  on = 1 runs the CPU's formula as written (~1e-14,
+ * about twice the time of the frequency kernel).  No effect with a seed (gain-only mode). */
+int rt_hip_plan_set_exact_emission(rt_hip_plan *plan, int on);
+
 /* Step safety factor c of the integrator (`c` of RayTrace_calc_ray, Helper.h:381;
  * create_image always uses 0.5, RayTrace::calc_ray_path passes its own).  0 < c < 1. */
 int rt_hip_plan_set_step_factor(rt_hip_plan *plan, double c);

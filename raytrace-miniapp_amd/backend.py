@@ -148,6 +148,11 @@ class Plan:
         return dict(image=image, I_ang=iang, failure_code=code.value, failed_rays=failed[:nf.value].copy(),
                     stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_})
 
+    def set_exact_emission(self, on: bool = True) -> "Plan":
+        """Emission mode: the CPU's per-frequency el/gl instead of the per-sub-segment ratio (include/rt_hip.h)."""
+        self.hl.check(self.hl.lib.rt_hip_plan_set_exact_emission(self._h, int(on)), "rt_hip_plan_set_exact_emission")
+        return self
+
     def set_step_factor(self, c: float) -> "Plan":
         self.hl.check(self.hl.lib.rt_hip_plan_set_step_factor(self._h, float(c)), "rt_hip_plan_set_step_factor")
         return self

@@ -159,6 +159,8 @@ def declare_hip_api(lib: C.CDLL) -> None:
     lib.rt_hip_plan_fetch_probe.argtypes = [vp, c_float_p, c_float_p, P(C.c_int32), P(RtRay),
                                             P(C.c_uint32), P(C.c_uint32)]
     lib.rt_hip_plan_fetch_probe.restype = C.c_int
+    lib.rt_hip_plan_set_exact_emission.argtypes = [vp, C.c_int]
+    lib.rt_hip_plan_set_exact_emission.restype = C.c_int
     lib.rt_hip_plan_set_step_factor.argtypes = [vp, C.c_double]
     lib.rt_hip_plan_set_step_factor.restype = C.c_int
     lib.rt_hip_plan_enable_path.argtypes = [vp, C.c_int]
@@ -174,6 +176,6 @@ HIP_API_SYMBOLS = [
     "rt_hip_device_count", "rt_hip_last_error", "rt_hip_selftest", "rt_hip_image_loop", "rt_hip_plan_create",
     "rt_hip_plan_set_rays", "rt_hip_plan_set_ray_grid", "rt_hip_plan_run", "rt_hip_plan_fetch",
     "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
-    "rt_hip_plan_fetch_probe", "rt_hip_plan_set_step_factor", "rt_hip_plan_enable_path",
+    "rt_hip_plan_fetch_probe", "rt_hip_plan_set_exact_emission", "rt_hip_plan_set_step_factor", "rt_hip_plan_enable_path",
     "rt_hip_plan_fetch_path", "rt_hip_plan_destroy",
 ]

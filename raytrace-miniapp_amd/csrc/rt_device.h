@@ -136,7 +136,8 @@ struct DevParams {
     // Kp = K rounded up to a multiple of 4: row stride of the lineshape tables and length of
     // the two per-frequency vectors (beam.dv, seed.f[4]) on the device, zero padded, so that the
     // frequency kernel always takes four frequencies per pass
-    int Kp, pad_kp;
+    int Kp;
+    int exact_emis; // emission mode: CPU formula with el/gl per frequency instead of the source-function form
     double scale;
     DevBeam beam;
     DevSeed seed;

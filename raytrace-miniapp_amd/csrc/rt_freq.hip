@@ -348,11 +348,14 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             gs[s]            = sl.g;
             const float e1   = sl.e;
             cs[s]            = sl.c;
-            rs[s]          = fabsf(gs[s]) >= RT_RS_MIN ? div_fast((double) e1, (double) gs[s]) : 0.0;
-            // a sub-segment the source-function form cannot take: gain sum tiny or NaN, but not the
-            // identity (both sums zero -- which ase_step reproduces: x = 0, e^x - 1 = 0)
-            irregular = irregular || (!(fabsf(gs[s]) >= RT_RS_MIN) && (gs[s] != 0.0f || e1 != 0.0f));
-            if (use_emis && fabsf(gs[s]) >= RT_RS_MIN)
+            // regular: the source-function form (ase_step) takes this sub-segment; not when the gain
+            // sum is tiny or NaN, and never in the exact mode (rt_hip_plan_set_exact_emission), which
+            // runs the CPU's own formula with its per-frequency division throughout
+            const bool regular = fabsf(gs[s]) >= RT_RS_MIN && !P.exact_emis;
+            rs[s]              = regular ? div_fast((double) e1, (double) gs[s]) : 0.0;
+            // (a sub-segment with both sums zero is the identity either way: x = 0, e^x - 1 = 0)
+            irregular = irregular || (!regular && (gs[s] != 0.0f || e1 != 0.0f));
+            if (use_emis && regular)
                 gs[s] = __builtin_amdgcn_fmed3f(gs[s], -P.gs_cap, P.gs_cap); // keeps |gs * gv| <= 708
         }
     }
@@ -401,7 +404,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     } else
 #pragma unroll
                     for (int s = 0; s < SF; s++) {
-                        if (fabsf(gs[s]) >= RT_RS_MIN) {
+                        if (fabsf(gs[s]) >= RT_RS_MIN && !P.exact_emis) {
                             ase_step(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
                             const float e1 = rec_slot(rec, s, SF, m.flags_steps, P.method == 1).e;
@@ -422,7 +425,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
                             wnan[j] = wnan[j] || w.v[j] != w.v[j];
-                        if (fabsf(g1) >= RT_RS_MIN) {
+                        if (fabsf(g1) >= RT_RS_MIN && !P.exact_emis) {
                             const double r1 = div_fast((double) e1, (double) g1);
                             ase_step(Iv, __builtin_amdgcn_fmed3f(g1, -P.gs_cap, P.gs_cap), r1, w.v, tab);
                         } else if (g1 != 0.0f || e1 != 0.0f) {

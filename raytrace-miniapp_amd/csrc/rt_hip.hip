@@ -835,6 +835,14 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     return RT_OK;
 }
 
+int rt_hip_plan_set_exact_emission(rt_hip_plan *p, int on)
+{
+    if (!p)
+        return fail_arg("rt_hip_plan_set_exact_emission: NULL plan");
+    p->P.exact_emis = on ? 1 : 0;
+    return RT_OK;
+}
+
 int rt_hip_plan_set_step_factor(rt_hip_plan *p, double c)
 {
     if (!p || !(c > 0.0) || !(c < 1.0))

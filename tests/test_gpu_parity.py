@@ -85,3 +85,19 @@ def test_selftest_of_exact_shortcuts_on_the_device(hip):
     n, bad = hip.HipLibrary.get().selftest(0)
     assert n == (0x3f880000 - 0x3f700000) + (1 << 24)
     assert bad == 0
+
+
+def test_exact_emission_mode_matches_the_cpu_loop_to_rounding(hip, oracle, ase_small, ase_ref):
+    """rt_hip_plan_set_exact_emission: the CPU's per-frequency el/gl (Helper.h:549-557) instead of the
+    per-sub-segment source function -- the whole ASE_small image against the reference's CPU loop
+    at the level of f64 summation order and libm differences, and the default mode beside it."""
+    with hip.Plan(ase_small) as plan:
+        plan.set_ray_grid()
+        fast = plan.run().fetch()
+        exact = plan.set_exact_emission(True).run().fetch()
+        again = plan.set_exact_emission(False).run().fetch()
+    assert rel_l2(exact["image"], ase_ref["image"]) < 1e-11 and rel_l2(exact["I_ang"], ase_ref["I_ang"]) < 1e-11
+    assert rel_l2(fast["image"], ase_ref["image"]) < TOL_TIGHT
+    assert 1e-12 < rel_l2(fast["image"], exact["image"]) < TOL_TIGHT      # the two modes do differ, by a float rounding
+    assert rel_l2(again["image"], fast["image"]) < 1e-13
+    assert exact["stats"]["cell_steps"] == fast["stats"]["cell_steps"]
