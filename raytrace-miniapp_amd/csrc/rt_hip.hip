@@ -634,6 +634,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     P.blob_bytes = (unsigned) blob.size();
     if (const char *dbg = getenv("RT_HIP_DEBUG"))
         P.debug = (unsigned) strtoul(dbg, nullptr, 0);
+    if (const char *ex = getenv("RT_HIP_EXACT_EMISSION")) // the loop signature has no parameter for it
+        P.exact_emis = atoi(ex) ? 1 : 0;
 
     p->beam_x.assign(beam->x, beam->x + beam->nx);
     p->beam_y.assign(beam->y, beam->y + beam->ny);
