@@ -118,12 +118,33 @@ def assemble(problem: Problem, tile_image, tile_iang, rank: int, world: int, gro
         pad = torch.zeros((b.ny, ncol_max - ncol, b.nv), dtype=tile.dtype, device=tile.device)
         tile = torch.cat([tile, pad], dim=1)
     tile = tile.contiguous()
-    if rank == dst:
-        parts = [torch.empty_like(tile) for _ in range(world)]
-        dist.gather(tile, gather_list=parts, dst=dst, group=group)
-        full = torch.empty((b.ny, b.nx, b.nv), dtype=tile.dtype, device=tile.device)
-        for r in range(world):
-            full[:, r::world, :] = parts[r][:, :tile_columns(b.nx, r, world), :]
-        return full.reshape(-1), iang
-    dist.gather(tile, gather_list=None, dst=dst, group=group)
-    return None, None
+    parts = _gather_tiles(tile, rank, world, dst, group)
+    if rank != dst:
+        return None, None
+    full = torch.empty((b.ny, b.nx, b.nv), dtype=tile.dtype, device=tile.device)
+    for r in range(world):
+        full[:, r::world, :] = parts[r][:, :tile_columns(b.nx, r, world), :]
+    return full.reshape(-1), iang
+
+
+_GATHER_OK = True
+
+
+def _gather_tiles(tile, rank: int, world: int, dst: int, group):
+    """Tiles of all ranks on rank dst (list), None elsewhere.  A gather to one root is all the path
+    needs (each peer has its own xGMI link to the root); should the backend refuse `gather`, every
+    rank falls back to `all_gather` -- the tiles are small -- and keeps doing so."""
+    global _GATHER_OK
+    import torch
+    import torch.distributed as dist
+
+    if _GATHER_OK:
+        try:
+            parts = [torch.empty_like(tile) for _ in range(world)] if rank == dst else None
+            dist.gather(tile, gather_list=parts, dst=dst, group=group)
+            return parts
+        except (RuntimeError, NotImplementedError):
+            _GATHER_OK = False
+    parts = [torch.empty_like(tile) for _ in range(world)]
+    dist.all_gather(parts, tile, group=group)
+    return parts if rank == dst else None
