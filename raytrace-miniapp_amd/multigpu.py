@@ -121,9 +121,13 @@ def assemble(problem: Problem, tile_image, tile_iang, rank: int, world: int, gro
     parts = _gather_tiles(tile, rank, world, dst, group)
     if rank != dst:
         return None, None
-    full = torch.empty((b.ny, b.nx, b.nv), dtype=tile.dtype, device=tile.device)
-    for r in range(world):
-        full[:, r::world, :] = parts[r][:, :tile_columns(b.nx, r, world), :]
+    if b.nx % world == 0:
+        # equal tiles: column i = r + world * c  <=>  stack the tiles behind the column axis (one kernel)
+        full = torch.stack(parts, dim=2).reshape(b.ny, b.nx, b.nv)
+    else:
+        full = torch.empty((b.ny, b.nx, b.nv), dtype=tile.dtype, device=tile.device)
+        for r in range(world):
+            full[:, r::world, :] = parts[r][:, :tile_columns(b.nx, r, world), :]
     return full.reshape(-1), iang
 
 
