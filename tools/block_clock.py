@@ -1,4 +1,4 @@
-"""Diagnostic: wave clock per block of the march loop (build: hipcc ... -DRT_TIMEBLOCKS -o librt_hip_time.so)."""
+"""Diagnostic: wave clock per block of the march loop (make -C raytrace-miniapp_amd/csrc librt_hip_time.so)."""
 import ctypes as C, importlib, sys
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")
