@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     // cell
     int c00 = 0;                              // index of the lower-left corner node of the current cell
     double n00 = 1, n10 = 1, n01 = 1, n11 = 1; // refractive index at its four corners (gathered in [A2] with g0, E0)
+    float f00 = 1, f10 = 1, f01 = 1, f11 = 1;  // the same rounded to float (Helper.h:332), once per cell
     double xc0 = 0, yc0 = 0;  // lower-left corner coordinates of the current cell
     double rwx = 1, rwy = 1;  // 1/(double)wx, 1/(double)wy of the current cell
     float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
@@ -432,6 +433,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     n10       = a10.n;
                     n01       = a01.n;
                     n11       = a11.n;
+                    f00       = (float) n00;
+                    f10       = (float) n10;
+                    f01       = (float) n01;
+                    f11       = (float) n11;
                     xc0       = X.lo;
                     yc0       = Y.lo;
                     rwx       = X.rw;
@@ -499,7 +504,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             const double dwx = (double) wx, dwy = (double) wy;
             const float u    = (float) div_by_recip<true>((double) px - xc0, dwx, rwx);
             const float v    = (float) div_by_recip<true>((double) ya - yc0, dwy, rwy);
-            n0  = lerp2(u, v, (float) n00, (float) n10, (float) n01, (float) n11);
+            n0  = lerp2(u, v, f00, f10, f01, f11);
             gxn = (float) (div_by_recip<true>((1.0 - (double) v) * (n10 - n00), dwx, rwx) +
                            div_by_recip<true>((double) v * (n11 - n01), dwx, rwx));
             gyn = (float) (div_by_recip<true>((1.0 - (double) u) * (n01 - n00), dwy, rwy) +
