@@ -249,8 +249,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     bool escaped = false, any_nz = false, mirror = false;
     // cell
     int c00 = 0;                              // index of the lower-left corner node of the current cell
-    double n00 = 1, n10 = 1, n01 = 1, n11 = 1; // refractive index at its four corners (gathered in [A2] with g0, E0)
-    float f00 = 1, f10 = 1, f01 = 1, f11 = 1;  // the same rounded to float (Helper.h:332), once per cell
+    // refractive index at the cell's four corners (gathered in [A2] with g0, E0), as block [B] uses it:
+    // rounded to float (Helper.h:332) and as the four f64 edge differences of Helper.h:333-334
+    float f00 = 1, f10 = 1, f01 = 1, f11 = 1;
+    double dnx0 = 0, dnx1 = 0, dny0 = 0, dny1 = 0; // n10 - n00, n11 - n01, n01 - n00, n11 - n10
     double xc0 = 0, yc0 = 0;  // lower-left corner coordinates of the current cell
     double rwx = 1, rwy = 1;  // 1/(double)wx, 1/(double)wy of the current cell
     float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
@@ -429,14 +431,14 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                         a01 = node[c00 + G.Nx];
                         a11 = node[c00 + G.Nx + 1];
                     }
-                    n00       = a00.n;
-                    n10       = a10.n;
-                    n01       = a01.n;
-                    n11       = a11.n;
-                    f00       = (float) n00;
-                    f10       = (float) n10;
-                    f01       = (float) n01;
-                    f11       = (float) n11;
+                    f00       = (float) a00.n;
+                    f10       = (float) a10.n;
+                    f01       = (float) a01.n;
+                    f11       = (float) a11.n;
+                    dnx0      = a10.n - a00.n;
+                    dnx1      = a11.n - a01.n;
+                    dny0      = a01.n - a00.n;
+                    dny1      = a11.n - a10.n;
                     xc0       = X.lo;
                     yc0       = Y.lo;
                     rwx       = X.rw;
@@ -505,10 +507,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             const float u    = (float) div_by_recip<true>((double) px - xc0, dwx, rwx);
             const float v    = (float) div_by_recip<true>((double) ya - yc0, dwy, rwy);
             n0  = lerp2(u, v, f00, f10, f01, f11);
-            gxn = (float) (div_by_recip<true>((1.0 - (double) v) * (n10 - n00), dwx, rwx) +
-                           div_by_recip<true>((double) v * (n11 - n01), dwx, rwx));
-            gyn = (float) (div_by_recip<true>((1.0 - (double) u) * (n01 - n00), dwy, rwy) +
-                           div_by_recip<true>((double) u * (n11 - n10), dwy, rwy));
+            gxn = (float) (div_by_recip<true>((1.0 - (double) v) * dnx0, dwx, rwx) +
+                           div_by_recip<true>((double) v * dnx1, dwx, rwx));
+            gyn = (float) (div_by_recip<true>((1.0 - (double) u) * dny0, dwy, rwy) +
+                           div_by_recip<true>((double) u * dny1, dwy, rwy));
             if (mirror && py < 0)
                 gyn = -gyn;
             lim2  = dzrem - zc;
