@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     const bool backward   = P.method == 1;
     const bool use_emis   = P.use_emis != 0;
     const unsigned CH     = P.chunk;
-    const int REFILL      = 8; // refill when this many lanes are idle (or the wave is empty)
+#ifndef RT_REFILL
+#define RT_REFILL 8
+#endif
+    const int REFILL      = RT_REFILL; // refill when this many lanes are idle (or the wave is empty)
 
     // ---- tables: copy the march blob to LDS once per work-group ----
     const unsigned char *tab;
