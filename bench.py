@@ -1,78 +1,184 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the ray-trace imaging hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
+                  [--workload standin|seed_medium|config5] [--no-cpu-baseline] [--no-config5]
 
-A *step* is one pass of the hot path (zero outputs + trace kernel [+ the RCCL
-assembly of image tiles when N > 1]) over the workload, with every input
-already resident in HBM.
+N > 1 may be started either way:
+  * `python bench.py --gpus N ...`  -- this process spawns the N ranks itself (a
+    `torch.distributed.run` child, started before anything here touches the GPU) and exits
+    with the child's code;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` -- one rank
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-Workload (BASELINE.json metric: "ray-steps/sec for ASE_medium"): ASE_medium.dat
-is absent from the reference checkout (.MISSING_LARGE_BLOBS), so the workload
-is the stand-in SURVEY.md 8(d) prescribes: ASE_small's plasma tables on the
-reference's own enlargement rule scale_problem(16) -> euv grid 120x50x38x28 =
-6,384,000 rays, nv = 52, N = 3.  At N > 1 the image gets N times as many pixel
-columns (weak scaling: 6,384,000 rays per GPU); columns are dealt round-robin
-to the ranks, each rank traces its tile, tiles are gathered to rank 0 over RCCL
-and I_ang is sum-reduced.
+A *step* is one pass of the hot path (zero outputs + march kernel + frequency kernel [+ the RCCL
+assembly of the image tiles when N > 1]) over the workload, every input resident in HBM.
 
-One JSON line is printed by rank 0; see DESIGN.md "Measurement" for the fields.
+Workloads (BASELINE.json `configs`):
+  standin      configs[2]/[3], the metric's workload: ASE_medium.dat is absent from the reference
+               checkout (.MISSING_LARGE_BLOBS), so this is the stand-in SURVEY.md 8(d) prescribes --
+               ASE_small's plasma tables on the reference's own enlargement rule scale_problem(16):
+               euv grid 120 x 50 x 38 x 28 = 6,384,000 rays, nv = 52, N = 3.
+  seed_medium  the seeded analogue, seed_small x scale_problem(16) = 124,848,000 rays.
+  config5      configs[4]: synthetic 4096 x 4096 pixels x 512 frequencies, na = nb = 1 (68.7 GB image).
+N > 1: pixel columns (seeded: source columns) are dealt round-robin to the ranks.  `--scaling
+strong` (default for N > 1, BASELINE config 4) splits the fixed workload; `--scaling weak` gives
+every rank the whole single-GPU workload (N times as many columns).  Tiles are assembled on rank 0
+with ONE collective per step: gather of (tile | I_ang) buffers (ASE) or sum-reduce (seeded).
+
+Rank 0 prints ONE JSON line; DESIGN.md section 5 describes every field.
 """
 from __future__ import annotations
 
 import argparse
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
 from pathlib import Path
 
-import numpy as np
-
 ROOT = Path(__file__).resolve().parent
-sys.path.insert(0, str(ROOT))
-rt = importlib.import_module("raytrace-miniapp_amd")
-backend = importlib.import_module("raytrace-miniapp_amd.backend")
-multigpu = importlib.import_module("raytrace-miniapp_amd.multigpu")
-problem_mod = importlib.import_module("raytrace-miniapp_amd.problem")
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 1024          # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 
 
-def algorithmic_read_bytes(n_rays: int, cell_steps: int, L: int, K: int, seeded: bool, n_live: int = 0) -> dict:
-    """B_read = 16 R + C_step S + 4 K 3 L R [+ (256 + 8K) R_live],
-    split between the two kernels of the path: the march gathers the plasma grid
-    (16 R + C_step S), the frequency pass reads the lineshape rows (4 K 3 L R)."""
+# --------------------------------------------------------------------------- self-launch
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the ranks as a torch.distributed.run
+    child.  Nothing in this process has touched HIP (torch is not even imported yet), so the
+    children are fresh processes, not re-execs of a GPU-initialised one."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())]
+    cmd += sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------- accounting
+def algorithmic_bytes(n_rays: int, cell_steps: int, L: int, K: int, seeded: bool, n_live: int, n_pix: int,
+                      n_ang: int) -> dict:
+    """B_read = 16 R + C_step S + 4 K 3 L R [+ (256 + 8K) R_live], split between the
+    two kernels of the path: the march gathers the plasma grid (16 R + C_step S), the frequency pass
+    reads the lineshape rows (4 K 3 L R) and, seeded, the seed tables.  B_write = 8 (nx ny K + na nb)."""
     c_step = 80 if seeded else 96
     march = 16 * n_rays + c_step * cell_steps
     freq = 4 * K * 3 * L * n_rays + ((256 + 8 * K) * n_live if seeded else 0)
-    return {"march": march, "freq": freq, "path": march + freq}
+    return {"march": march, "freq": freq, "path": march + freq, "write": 8 * (n_pix * K + n_ang)}
 
 
-def build_workload(world: int):
+def committed_counters() -> dict:
+    """Counter passes are separate rocprofv3 runs (MI355X_MICROARCH.md); their summary is committed
+    under profiles/ and quoted here with its source.  Returns {} when there is none."""
+    for name in ("r02_pmc.json", "r01_pmc.json"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            try:
+                d = json.loads(f.read_text())
+                d["_source"] = f"profiles/{name}"
+                return d
+            except Exception:  # noqa: BLE001
+                pass
+    return {}
+
+
+# --------------------------------------------------------------------------- workloads
+def build_workload(rt, problem_mod, name: str, world: int, scaling: str):
     base = rt.datfile.load(ROOT / "tests" / "golden" / "ASE_small.dat.xz")
-    med = rt.scale_problem(base, 16.0)
-    if world > 1:
-        med = problem_mod.regrid_beam(med, nx=med.beam.nx * world)
-    med.label = "ASE_medium stand-in: ASE_small tables x scale_problem(16)" + (
-        f", nx x{world} (weak scaling)" if world > 1 else "")
-    return med
+    if name == "standin":
+        p = rt.scale_problem(base, 16.0)
+        label = "ASE_medium stand-in: ASE_small tables x scale_problem(16)"
+        data = ("ASE_small.dat plasma tables (reference input) on the synthetic scale_problem(16) ray grid; "
+                "ASE_medium.dat itself is absent from the reference checkout")
+    elif name == "seed_medium":
+        p = rt.scale_problem(rt.datfile.load(ROOT / "tests" / "golden" / "seed_small.dat.xz"), 16.0)
+        label = "seed_medium stand-in: seed_small tables x scale_problem(16)"
+        data = "seed_small.dat tables (reference input) on the synthetic scale_problem(16) seed-beam grid"
+    elif name == "config5":
+        p = config5_problem(rt, problem_mod, 4096)
+        label = "synthetic 4096x4096 pixels x 512 frequencies, na = nb = 1 (BASELINE config 5)"
+        data = "ASE_small.dat plasma tables with the frequency axis resampled 52 -> 512, one ray per pixel"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    if world > 1 and scaling == "weak":
+        if p.seed is None:
+            p = problem_mod.regrid_beam(p, nx=p.beam.nx * world)
+        else:
+            p = problem_mod.regrid_seed_beam(p, nx=p.seed_beam.nx * world)
+        label += f", nx x{world} (weak scaling)"
+    p.label = label
+    return p, data
+
+
+def config5_problem(rt, problem_mod, n: int):
+    base = rt.datfile.load(ROOT / "tests" / "golden" / "ASE_small.dat.xz")
+    return problem_mod.regrid_beam(problem_mod.resample_frequency(base, 512), nx=n, ny=n, a_centre=-1.0,
+                                   b_centre=-4.5)
+
+
+# --------------------------------------------------------------------------- probes on the box
+def measure_hbm_peak(torch, dev) -> dict:
+    """Device-to-device copy of 2 GiB (read + write counted) and a read-only pass: what this box's HBM
+    delivers to a trivially coalesced kernel, quoted beside the 8 TB/s spec."""
+    n = (2 << 30) // 8
+    a = torch.empty(n, dtype=torch.float64, device=dev).normal_()
+    b = torch.empty_like(a)
+    best_copy = best_read = 1e9
+    for _ in range(6):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        a.sum()
+        e2.record()
+        torch.cuda.synchronize()
+        best_copy = min(best_copy, e0.elapsed_time(e1))
+        best_read = min(best_read, e1.elapsed_time(e2))
+    del a, b
+    torch.cuda.empty_cache()
+    return {"copy_GBs": 2 * n * 8 / best_copy / 1e6, "read_GBs": n * 8 / best_read / 1e6,
+            "how": "torch D2D copy of 2 GiB (read + write bytes) / torch.sum of 2 GiB (read bytes), best of 6, HIP events"}
+
+
+def cpu_info() -> dict:
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "available": avail}
 
 
 def cpu_baseline(problem, cell_steps: int) -> dict:
-    """Rank 0, N = 1 only.  Times the UNMODIFIED reference RayTraceImageCPULoop
-    (oracle/_ref/librt_ref.so, kind "reference") if it travelled to this box,
-    else our bit-identical C restatement (kind "port"), on the whole workload,
-    split in contiguous ray chunks over host threads exactly as the reference's
-    `threads` method does (RayTraceImage.cpp:89-134)."""
+    """Rank 0, N = 1 only.  Times the UNMODIFIED reference RayTraceImageCPULoop (oracle/_ref/librt_ref.so,
+    kind "reference") if it travelled to this box, else our bit-identical C restatement (kind "port"):
+      * all host cores: the whole workload in contiguous ray chunks, one per thread, exactly as the
+        reference's `threads` method splits it (RayTraceImage.cpp:89-134), 3 runs;
+      * 1 core: every 16th pixel's rays (a strided sample of the same workload), 3 runs, scaled by the
+        sample's own ray-step count."""
+    import numpy as np
     from oracle.binding import Oracle, Reference
 
+    info = cpu_info()
     rays = problem.build_rays()
     n = len(rays)
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = max(1, min(16, info["available"]))
     chunk = n // cores + 1
     if Reference.available():
         kind, eng = "reference", Reference()
@@ -82,55 +188,152 @@ def cpu_baseline(problem, cell_steps: int) -> dict:
         run = lambda r: eng.image_loop(problem, r, n_threads=1)  # noqa: E731
     parts = [rays[i * chunk:(i + 1) * chunk] for i in range(cores)]
     parts = [p for p in parts if len(p)]
-    th = [threading.Thread(target=run, args=(p,)) for p in parts]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    return {"value": cell_steps / dt, "unit": "ray-steps/s", "cores": len(parts), "kind": kind,
-            "seconds": dt, "ms_per_image": dt * 1e3,
+    times = []
+    for _ in range(3):
+        th = [threading.Thread(target=run, args=(p,)) for p in parts]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        times.append(time.perf_counter() - t0)
+    # 1 core on a strided pixel sample
+    per_pixel = problem.beam.na * problem.beam.nb if problem.seed is None else problem.seed_beam.na * problem.seed_beam.nb
+    n_pix = n // per_pixel
+    pix = np.arange(0, n_pix, 16, dtype=np.int64)
+    ids = (pix[:, None] * per_pixel + np.arange(per_pixel)[None, :]).reshape(-1)
+    sample = problem.build_rays(ids)
+    steps_sample = int(Oracle().image_loop(problem, sample, n_threads=cores)["counters"]["cell_steps"])
+    t1 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run(sample)
+        t1.append(time.perf_counter() - t0)
+    return {"value": cell_steps / min(times), "unit": "ray-steps/s", "cores": len(parts), "kind": kind,
+            "seconds_min": min(times), "seconds_mean": sum(times) / len(times), "runs": len(times),
+            "ms_per_image": min(times) * 1e3,
+            "one_core": {"value": steps_sample / min(t1), "unit": "ray-steps/s", "seconds_min": min(t1),
+                         "seconds_mean": sum(t1) / len(t1), "runs": len(t1),
+                         "sample": f"every 16th pixel: {len(sample)} rays, {steps_sample} ray-steps, one thread"},
+            "cpu_model": info["cpu_model"], "nproc": info["nproc"], "pinning": "none (OS scheduler)",
             "sample": f"whole workload ({n} rays, {cell_steps} ray-steps), contiguous chunks on "
                       f"{len(parts)} host threads; RayTraceImageCPULoop per chunk"}
 
 
-def main() -> None:
+def measure_image_loop(backend, problem) -> dict:
+    """ms/image as the reference harness times create_image's back-end call (CreateImage.cpp:147-152):
+    rt_hip_image_loop with host pointers -- table pack + upload, ray list hand-over, kernels, download.
+    PCIe-inclusive; never `value`."""
+    rays = problem.build_rays()
+    backend.image_loop(problem, rays)
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        out = backend.image_loop(problem, rays)
+        t.append((time.perf_counter() - t0) * 1e3)
+    return {"ms_min": min(t), "ms_mean": sum(t) / len(t), "runs": len(t), "kernel_ms": out["stats"]["kernel_ms"],
+            "what": "rt_hip_image_loop (host-pointer C ABI behind RayTraceImageHipLoop): pack + upload tables, "
+                    f"{len(rays)}-ray list handed over as host memory, kernels, download"}
+
+
+def measure_config5(torch, backend, rt, problem_mod, dev, counters: dict) -> dict:
+    """BASELINE config 5 on one GPU: 16,777,216 rays, nv = 512, the image (68.7 GB) is written once."""
+    p = config5_problem(rt, problem_mod, 4096)
+    b = p.beam
+    image = torch.empty(b.nx * b.ny * b.nv, dtype=torch.float64, device=dev)
+    iang = torch.zeros(b.na * b.nb, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    with backend.Plan(p, device=dev.index or 0) as plan:
+        plan.set_ray_grid()
+        ms = []
+        for i in range(4):
+            plan.run(stream, image.data_ptr(), iang.data_ptr())
+            m, f = plan.kernel_times()
+            if i:
+                ms.append((m, f))
+        st = plan.fetch(want_image=False)["stats"]
+        # size-independent property at full size, on the device: sum(I_ang) = sum_pixels sum_k 2 dv_k image
+        dv2 = torch.tensor(2.0 * p.beam.dv, dtype=torch.float64, device=dev)
+        lhs = float(iang.sum().item())
+        rhs = float((image.view(-1, b.nv) * dv2[None, :]).sum().item())
+    del image
+    torch.cuda.empty_cache()
+    march = min(m for m, _ in ms)
+    freq = min(f for _, f in ms)
+    alg = algorithmic_bytes(st["n_rays"], st["cell_steps"], p.N - 1, b.nv, False, 0, b.nx * b.ny, b.na * b.nb)
+    t = (march + freq) * 1e-3
+    rec = {"workload": "synthetic 4096x4096x512, na = nb = 1", "rays": st["n_rays"], "ray_steps": st["cell_steps"],
+           "march_ms": march, "freq_ms": freq, "kernel_ms": march + freq,
+           "algorithmic_read_bytes": alg["path"], "algorithmic_write_bytes": alg["write"],
+           "bound": "hbm", "achieved": alg["path"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg["path"] / t / 1e9 / HBM_PEAK_GBS,
+           "read_plus_write_GBs": (alg["path"] + alg["write"]) / t / 1e9, "store_GBs": alg["write"] / t / 1e9,
+           "ray_steps_per_sec": st["cell_steps"] / t,
+           "iang_identity_rel_err": abs(lhs - rhs) / abs(rhs) if rhs else None,
+           "limiter": f"{st['n_rays'] * 6 * b.nv / 1e9:.1f} G float64 exponential updates (f64 VALU issue) beside "
+                      f"{alg['write'] / 1e9:.1f} GB of stores; not HBM reads"}
+    c5 = counters.get("config5", {})
+    rec["traffic"] = c5.get("hbm_bytes_per_step")
+    rec["traffic_source"] = (counters.get("_source") + " (config5 counter pass)") if c5 else None
+    return rec
+
+
+# --------------------------------------------------------------------------- main
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
+    ap.add_argument("--workload", choices=("standin", "seed_medium", "config5"), default="standin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 sub-record of the default N = 1 run")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed loop (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+
+    import importlib
+
+    import numpy as np
     import torch
     import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    rt = importlib.import_module("raytrace-miniapp_amd")
+    backend = importlib.import_module("raytrace-miniapp_amd.backend")
+    multigpu = importlib.import_module("raytrace-miniapp_amd.multigpu")
+    problem_mod = importlib.import_module("raytrace-miniapp_amd.problem")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    full = build_workload(world)
+    full, data = build_workload(rt, problem_mod, args.workload, world, scaling)
     mine = multigpu.shard(full, rank, world)
     b = mine.beam
+    seeded = mine.seed is not None
     plan = backend.Plan(mine, device=local)
     plan.set_ray_grid()
-    image = torch.zeros(b.nx * b.ny * b.nv, dtype=torch.float64, device=dev)
-    iang = torch.zeros(b.na * b.nb, dtype=torch.float64, device=dev)
+    n_ang = b.na * b.nb
+    # one buffer per rank, (tile | I_ang): the assembly is ONE collective
+    asm = multigpu.Assembler(full, rank, world, dev)
+    image, iang = asm.image, asm.iang
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         plan.run(stream, image.data_ptr(), iang.data_ptr())
         if world > 1:
-            multigpu.assemble(full, image, iang, rank, world)
+            asm.assemble()
         return plan.kernel_times()  # HIP events on the launch stream, recorded around each kernel
 
     for _ in range(args.warmup):
@@ -151,34 +354,48 @@ def main() -> None:
 
     st = plan.fetch(want_image=False)
     stats = st["stats"]
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([float(stats["cell_steps"]), float(stats["n_rays"])], dtype=torch.float64, device=dev)
+    march_ms = float(np.mean([k[0] for k in kms]))
+    freq_ms = float(np.mean([k[1] for k in kms]))
+    t = torch.tensor([dt, march_ms + freq_ms], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([float(stats["cell_steps"]), float(stats["n_rays"]), float(stats["n_rays"] - stats["n_escaped"])],
+                       dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dt_max = float(t.item())
+    dt_max, kernel_ms_max = float(t[0].item()), float(t[1].item())
     steps_all, rays_all = int(cnt[0].item()), int(cnt[1].item())
 
+    rc = 0
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
-        march_ms = float(np.mean([k[0] for k in kms]))
-        freq_ms = float(np.mean([k[1] for k in kms]))
         kernel_ms = march_ms + freq_ms
         L, K = mine.N - 1, b.nv
-        alg = algorithmic_read_bytes(stats["n_rays"], stats["cell_steps"], L, K, mine.seed is not None)
-        traffic = {}
-        tf = ROOT / "profiles" / "traffic_latest.json"
-        if tf.exists() and world == 1:
-            try:
-                traffic = json.loads(tf.read_text()).get("kernels", {})
-            except Exception:  # noqa: BLE001
-                traffic = {}
+        n_live = stats["n_rays"] - stats["n_escaped"]
+        alg = algorithmic_bytes(stats["n_rays"], stats["cell_steps"], L, K, seeded, n_live, b.nx * b.ny, n_ang)
+        counters = committed_counters() if (world == 1 and args.workload == "standin") else {}
+        hbm = counters.get("hbm", {})
+        sq = counters.get("pmc_sq", {})
 
         def roof(name, kname, ms):
             ach = alg[name] / (ms * 1e-3) / 1e9
-            return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic.get(kname), "kernel": kname, "kernel_ms_avg": ms,
-                    "algorithmic_bytes_per_launch": alg[name]}
+            r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                 "traffic": hbm.get(kname, {}).get("hbm_bytes_per_launch"),
+                 "traffic_source": (counters["_source"] + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                    "command, gfx950 corrections applied; not measured in this run") if kname in hbm else None,
+                 "kernel": kname, "kernel_ms_avg": ms, "algorithmic_bytes_per_launch": alg[name]}
+            c = sq.get(kname, {}).get("avg", {})
+            if c.get("SQ_INSTS_VALU"):
+                # what actually binds the kernel: wave-instructions issued per SIMD (every class takes an
+                # issue slot, tools/ubench/issue_cost.hip); peak = one instruction per 2 cycles per SIMD
+                instr = c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_SALU", 0.0)
+                clock = counters.get("shader_clock_hz", 2.4e9)
+                rate = instr / (ms * 1e-3)
+                peak = N_SIMD * clock / 2.0
+                r["secondary"] = {"bound": "valu+salu issue", "achieved": rate / 1e9, "peak": peak / 1e9,
+                                  "unit": "G wave-instr/s", "frac": rate / peak,
+                                  "valu_instr_per_launch": c["SQ_INSTS_VALU"], "salu_instr_per_launch": c.get("SQ_INSTS_SALU"),
+                                  "source": counters["_source"] + " (committed SQ counter pass, instruction counts per launch)"}
+            return r
 
         kernels = [roof("march", "rt_march_kernel", march_ms), roof("freq", "rt_freq_kernel", freq_ms)]
         dominant = max(kernels, key=lambda r: r["kernel_ms_avg"])
@@ -186,16 +403,15 @@ def main() -> None:
         line = {
             "metric": "ray_steps_per_sec", "value": steps_all / (dt_max / args.steps), "unit": "ray-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "ms_per_image": ms_step, "kernel_ms": kernel_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "kernel_ms": kernel_ms_max, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32+f64",  # float32 march (bit-exact), float64 frequency integration
-            "data": "ASE_small.dat plasma tables (reference input) on the synthetic scale_problem(16) ray grid; "
-                    "ASE_medium.dat itself is absent from the reference checkout",
+            "data": data,
             "config": {"workload": full.label, "rays_per_gpu": stats["n_rays"], "rays_total": rays_all,
                        "ray_steps_total": steps_all, "nv": K, "N": mine.N,
-                       "image": [full.beam.ny, full.beam.nx, K], "parallelism": f"pixel-columns x{world}"},
-            # the dominant kernel, as the contract asks; every kernel of the path and the
-            # path as a whole are listed next to it
+                       "image": [full.beam.ny, full.beam.nx, K],
+                       "parallelism": ("pixel" if not seeded else "source") + f"-columns x{world}"},
+            # the dominant kernel, as the contract asks; every kernel of the path and the path as a
+            # whole are listed next to it
             "roofline": dominant,
             "roofline_kernels": kernels,
             "roofline_path": {"bound": "hbm", "achieved": path_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -203,16 +419,40 @@ def main() -> None:
                               "algorithmic_bytes": alg["path"],
                               "bytes_per_ray_step": alg["path"] / max(1, stats["cell_steps"])},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:
+            line["multi_gpu"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "kernel_ms_max_over_ranks": kernel_ms_max,
+                                 "assembly_ms": max(0.0, ms_step - kernel_ms_max),
+                                 "collective": asm.describe()}
+        if world == 1 and not args.no_extras:
             try:
-                line["cpu_baseline"] = cpu_baseline(mine, stats["cell_steps"])
+                line["peak_measured"] = measure_hbm_peak(torch, dev)
             except Exception as exc:  # noqa: BLE001
-                line["cpu_baseline"] = {"error": repr(exc)}
+                line["peak_measured"] = {"error": repr(exc)}
+            try:
+                il = measure_image_loop(backend, mine)
+                line["ms_per_image"] = il["ms_min"]
+                line["image_loop"] = il
+            except Exception as exc:  # noqa: BLE001
+                line["image_loop"] = {"error": repr(exc)}
+            if args.workload == "standin" and not args.no_config5:
+                plan.close()
+                try:
+                    line["roofline_config5"] = measure_config5(torch, backend, rt, problem_mod, dev, counters)
+                except Exception as exc:  # noqa: BLE001
+                    line["roofline_config5"] = {"error": repr(exc)}
+            if not args.no_cpu_baseline:
+                try:
+                    line["cpu_baseline"] = cpu_baseline(mine, stats["cell_steps"])
+                except Exception as exc:  # noqa: BLE001
+                    line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

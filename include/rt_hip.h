@@ -200,6 +200,10 @@ int rt_hip_plan_set_step_factor(rt_hip_plan *plan, double c);
 int rt_hip_plan_enable_path(rt_hip_plan *plan, int on);
 int rt_hip_plan_fetch_path(rt_hip_plan *plan, float *path, int32_t *err);
 
+/* Profiling aid (no reference counterpart): bit 0 = skip the frequency / deposit kernel, bit 1 = skip
+ * the march and run the frequency pass over the records of the previous run of this plan.  0 = normal. */
+int rt_hip_plan_set_debug(rt_hip_plan *plan, unsigned bits);
+
 void rt_hip_plan_destroy(rt_hip_plan *plan);
 
 #ifdef __cplusplus

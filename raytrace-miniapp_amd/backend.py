@@ -157,6 +157,11 @@ class Plan:
         self.hl.check(self.hl.lib.rt_hip_plan_set_step_factor(self._h, float(c)), "rt_hip_plan_set_step_factor")
         return self
 
+    def set_debug(self, bits: int) -> "Plan":
+        """Profiling aid: bit 0 skips the frequency kernel, bit 1 skips the march (include/rt_hip.h)."""
+        self.hl.check(self.hl.lib.rt_hip_plan_set_debug(self._h, int(bits)), "rt_hip_plan_set_debug")
+        return self
+
     def enable_path(self, on: bool = True) -> "Plan":
         self.hl.check(self.hl.lib.rt_hip_plan_enable_path(self._h, int(on)), "rt_hip_plan_enable_path")
         return self

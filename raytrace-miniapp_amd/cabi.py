@@ -167,6 +167,8 @@ def declare_hip_api(lib: C.CDLL) -> None:
     lib.rt_hip_plan_enable_path.restype = C.c_int
     lib.rt_hip_plan_fetch_path.argtypes = [vp, c_float_p, P(C.c_int32)]
     lib.rt_hip_plan_fetch_path.restype = C.c_int
+    lib.rt_hip_plan_set_debug.argtypes = [vp, C.c_uint]
+    lib.rt_hip_plan_set_debug.restype = C.c_int
     lib.rt_hip_plan_destroy.argtypes = [vp]
     lib.rt_hip_plan_destroy.restype = None
 
@@ -177,5 +179,5 @@ HIP_API_SYMBOLS = [
     "rt_hip_plan_set_rays", "rt_hip_plan_set_ray_grid", "rt_hip_plan_run", "rt_hip_plan_fetch",
     "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
     "rt_hip_plan_fetch_probe", "rt_hip_plan_set_exact_emission", "rt_hip_plan_set_step_factor", "rt_hip_plan_enable_path",
-    "rt_hip_plan_fetch_path", "rt_hip_plan_destroy",
+    "rt_hip_plan_fetch_path", "rt_hip_plan_set_debug", "rt_hip_plan_destroy",
 ]

@@ -318,7 +318,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     if (const char *e = getenv("RT_HIP_UPLOAD_SLICES")) // tuning
         n_launch = p->host_rays ? (unsigned) atoi(e) : 1u;
     n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
-    for (unsigned c = 0; c < n_launch && grid > 0; c++) {
+    for (unsigned c = 0; c < n_launch && grid > 0 && !(p->P.debug & 2u); c++) {
         const unsigned long long b = p->n_rays * c / n_launch, e = p->n_rays * (c + 1) / n_launch;
         if (p->host_rays) {
             HIP_TRY(hipMemcpy(p->rays_dev + b, p->host_rays + b, (size_t) (e - b) * sizeof(rt_ray), hipMemcpyHostToDevice));
@@ -853,6 +853,14 @@ int rt_hip_plan_set_step_factor(rt_hip_plan *p, double c)
     p->P.c_cap     = cf * 1.00001f;
     p->P.c_h1      = cf * 0.1f;
     p->P.c_h3      = cf * 0.05f;
+    return RT_OK;
+}
+
+int rt_hip_plan_set_debug(rt_hip_plan *p, unsigned bits)
+{
+    if (!p)
+        return fail_arg("rt_hip_plan_set_debug: NULL plan");
+    p->P.debug = bits;
     return RT_OK;
 }
 

@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     float px = 0, py = 0, pz = 0, sx = 0, sy = 0, sz = 1;
     float gacc = 0, eacc = 0;
     int cell_last = 0, n_done = 0;
+    unsigned char *recp = P.rec; // slot of the lane's current sub-segment inside its ray's record
     BlobGain G    = hdr[1]; // header of the lane's current length ii, re-read only when ii changes
     unsigned steps = 0;
     bool escaped = false, any_nz = false, mirror = false;
@@ -331,6 +332,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     pp[0]     = px;
                     pp[1]     = py;
                 }
+                // the record's slots are visited in marching order: up from slot 0, or down from slot S-1
+                recp      = P.rec + (size_t) ridx * P.rec_stride + (backward ? 12 * (S - 1) : 0);
                 seg       = 0;
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
@@ -357,15 +360,14 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // iteration (a lane that needs more -- several empty sub-segments in a row, or the
         // commit after an escape -- simply comes back next iteration).
         if (st == ST_CELL) {
-            unsigned char *rec = P.rec + (size_t) ridx * P.rec_stride;
             bool in_seg        = !escaped & (z < 0.995f * z_stop);
             if (!in_seg) {
-                // [A1] end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0)
-                const int is   = backward ? RT_N_SUB - iz - 1 : iz;
-                const int slot = (ii - 1) * RT_N_SUB + is;
+                // [A1] end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0),
+                // slot (ii - 1) * 3 + (backward ? 2 - iz : iz)
 #ifndef RT_ABL_NOSTORE
-                reinterpret_cast<RecSlot *>(rec)[slot] = RecSlot{ gacc, eacc, cell_last };
+                *reinterpret_cast<RecSlot *>(recp) = RecSlot{ gacc, eacc, cell_last };
 #endif
+                recp += backward ? -12 : 12;
                 any_nz    = any_nz | (gacc != 0.0f) | (eacc != 0.0f);
                 if (P.path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
                                  // segment records the same position, later segments stay zero
@@ -493,7 +495,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 m.sy          = sy;
                 m.sz          = sz;
                 m.flags_steps = fl | ((unsigned) n_done << REC_NDONE_SHIFT) | (steps << REC_STEPS_SHIFT);
-                *reinterpret_cast<RecMeta *>(rec + 12 * (size_t) S) = m;
+                // n_done slots were committed: recp stands n_done slots above slot 0 (forward) or below
+                // slot S-1 (backward); the meta block follows slot S-1
+                *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? n_done + 1 : S - n_done)) = m;
                 tot_steps += steps;
                 tot_esc += escaped ? 1u : 0u;
                 tot_skip += (fl & F_SKIP) ? 1u : 0u;
@@ -541,9 +545,34 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 #define RT_FDIV(a, b) ((a) / (b))
 #endif
                 const float rn = RT_FDIV(1.0f, n); // one IEEE division, three exact quotients
-                float t  = div_by_recip(sx * gxn + sy * gyn + 1e-12f, n, rn);
-                float fx = div_by_recip(gxn, n, rn) - sx * t;
-                float fy = div_by_recip(gyn, n, rn) - sy * t;
+                float a0 = sx * gxn + sy * gyn + 1e-12f;
+                float t  = div_by_recip<true>(a0, n, rn);
+                float qx = div_by_recip<true>(gxn, n, rn);
+                float qy = div_by_recip<true>(gyn, n, rn);
+#ifndef RT_ABL_NOGUARD
+                // div_by_recip needs a true division for non-zero dividends below 1e-29 (rt_math.h).  One
+                // wave-uniform test covers the three quotients: the smallest magnitude of the dividends is
+                // below the bound only where a lane holds an exact zero (index gradient of a uniform
+                // region; the quotient 0 is right as it is) or, once in a blue moon, such a dividend.
+                if (__ballot(fminf(fminf(fabsf(a0), fabsf(gxn)), fabsf(gyn)) < 1e-29f) != 0ull) {
+                    if (fabsf(a0) < 1e-29f && a0 != 0.0f) {
+                        asm volatile("" : "+v"(a0));
+                        t = a0 / n;
+                    }
+                    if (fabsf(gxn) < 1e-29f && gxn != 0.0f) {
+                        float g = gxn;
+                        asm volatile("" : "+v"(g));
+                        qx = g / n;
+                    }
+                    if (fabsf(gyn) < 1e-29f && gyn != 0.0f) {
+                        float g = gyn;
+                        asm volatile("" : "+v"(g));
+                        qy = g / n;
+                    }
+                }
+#endif
+                float fx = qx - sx * t;
+                float fy = qy - sy * t;
                 float fz = -sz * t;
                 float h  = RT_FDIV(P.c_h1, fabsf(t)); // c * 0.1f / |t|
                 h        = h < dzcap ? h : dzcap;

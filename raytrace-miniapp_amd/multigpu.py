@@ -91,64 +91,79 @@ def tile_columns(nx: int, rank: int, world: int) -> int:
     return len(range(rank, nx, world))
 
 
+class Assembler:
+    """Per-rank output buffer and the ONE collective per image that assembles it on rank `dst`.
+
+    Every rank traces its shard into `buffer` = (tile | pad | I_ang) -- `image` and `iang` are views of
+    it, handed to rt_hip_plan_run as device pointers -- and `assemble()` then issues
+      ASE    : a gather of the buffers to rank dst (each peer over its own xGMI link), followed on dst
+               by one interleave copy of the pixel-column tiles and one sum over the I_ang tails;
+      seeded : a sum-reduce of the buffers (full image | I_ang) to rank dst.
+    Backend "nccl" is RCCL on ROCm; the CPU tests run the same code over gloo."""
+
+    def __init__(self, problem: Problem, rank: int, world: int, device=None, group=None, dst: int = 0):
+        import torch
+
+        b = problem.beam
+        self.problem, self.rank, self.world, self.group, self.dst = problem, rank, world, group, dst
+        self.seeded = problem.seed is not None
+        self.n_ang = b.na * b.nb
+        self.ncol = tile_columns(b.nx, rank, world) if not self.seeded else b.nx
+        self.ncol_max = tile_columns(b.nx, 0, world) if not self.seeded else b.nx
+        self.n_tile = b.ny * self.ncol * b.nv
+        self.n_tile_max = b.ny * self.ncol_max * b.nv
+        dev = device if device is not None else torch.device("cpu")
+        self.buffer = torch.zeros(self.n_tile_max + self.n_ang, dtype=torch.float64, device=dev)
+        self.image = self.buffer[:self.n_tile]
+        self.iang = self.buffer[self.n_tile_max:]
+        self.recv = None
+        if world > 1 and not self.seeded and rank == dst:
+            self.recv = torch.empty((world, self.n_tile_max + self.n_ang), dtype=torch.float64, device=dev)
+
+    def describe(self) -> str:
+        n = (self.n_tile_max + self.n_ang) * 8
+        if self.seeded:
+            return f"reduce(sum, f64) of {n} B (image | I_ang) to rank {self.dst}"
+        return (f"gather of {n} B (pixel-column tile | I_ang) per rank to rank {self.dst}, one interleave copy, "
+                f"one I_ang sum")
+
+    def assemble(self, buffer=None):
+        """Returns (image, I_ang) flat tensors on rank dst, (None, None) elsewhere."""
+        import torch
+        import torch.distributed as dist
+
+        buf = self.buffer if buffer is None else buffer
+        b = self.problem.beam
+        if self.world == 1:
+            return buf[:self.n_tile], buf[self.n_tile_max:]
+        if self.seeded:
+            dist.reduce(buf, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group)
+            return (buf[:self.n_tile], buf[self.n_tile_max:]) if self.rank == self.dst else (None, None)
+        parts = list(self.recv.unbind(0)) if self.rank == self.dst else None
+        dist.gather(buf, gather_list=parts, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None, None
+        iang = self.recv[:, self.n_tile_max:].sum(0)
+        if b.nx % self.world == 0:
+            # equal tiles: column i = r + world * c  <=>  [rank][ny][c][k] -> [ny][c][rank][k], one copy
+            full = self.recv[:, :self.n_tile_max].view(self.world, b.ny, self.ncol_max, b.nv).permute(1, 2, 0, 3).reshape(-1)
+        else:
+            out = torch.empty((b.ny, b.nx, b.nv), dtype=buf.dtype, device=buf.device)
+            for r in range(self.world):
+                nc = tile_columns(b.nx, r, self.world)
+                out[:, r::self.world, :] = self.recv[r, :b.ny * nc * b.nv].view(b.ny, nc, b.nv)
+            full = out.reshape(-1)
+        return full, iang
+
+
 def assemble(problem: Problem, tile_image, tile_iang, rank: int, world: int, group=None, dst: int = 0):
-    """Assemble the final image on rank `dst` from per-rank results.
-
-    tile_image / tile_iang are torch tensors (device tensors under RCCL, CPU
-    tensors under gloo) holding this rank's result of shard(problem, rank, world).
-    Returns (image, I_ang) as flat tensors on rank dst, (None, None) elsewhere.
-    """
-    import torch
-    import torch.distributed as dist
-
-    b = problem.beam
-    if world == 1:
-        return tile_image.reshape(-1), tile_iang.reshape(-1)
-    iang = tile_iang.reshape(-1).clone()
-    dist.reduce(iang, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    if problem.seed is not None:
-        img = tile_image.reshape(-1).clone()
-        dist.reduce(img, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        return (img, iang) if rank == dst else (None, None)
-    # ASE: gather of equal-sized tiles (padded to the widest), then interleave
-    ncol_max = tile_columns(b.nx, 0, world)
-    ncol = tile_columns(b.nx, rank, world)
-    tile = tile_image.reshape(b.ny, ncol, b.nv)
-    if ncol != ncol_max:
-        pad = torch.zeros((b.ny, ncol_max - ncol, b.nv), dtype=tile.dtype, device=tile.device)
-        tile = torch.cat([tile, pad], dim=1)
-    tile = tile.contiguous()
-    parts = _gather_tiles(tile, rank, world, dst, group)
-    if rank != dst:
+    """Assemble the final image on rank `dst` from per-rank results held in separate tensors
+    (tile_image / tile_iang: device tensors under RCCL, CPU tensors under gloo).
+    Returns (image, I_ang) as flat tensors on rank dst, (None, None) elsewhere."""
+    a = Assembler(problem, rank, world, device=tile_image.device, group=group, dst=dst)
+    a.image.copy_(tile_image.reshape(-1))
+    a.iang.copy_(tile_iang.reshape(-1))
+    img, ang = a.assemble()
+    if img is None:
         return None, None
-    if b.nx % world == 0:
-        # equal tiles: column i = r + world * c  <=>  stack the tiles behind the column axis (one kernel)
-        full = torch.stack(parts, dim=2).reshape(b.ny, b.nx, b.nv)
-    else:
-        full = torch.empty((b.ny, b.nx, b.nv), dtype=tile.dtype, device=tile.device)
-        for r in range(world):
-            full[:, r::world, :] = parts[r][:, :tile_columns(b.nx, r, world), :]
-    return full.reshape(-1), iang
-
-
-_GATHER_OK = True
-
-
-def _gather_tiles(tile, rank: int, world: int, dst: int, group):
-    """Tiles of all ranks on rank dst (list), None elsewhere.  A gather to one root is all the path
-    needs (each peer has its own xGMI link to the root); should the backend refuse `gather`, every
-    rank falls back to `all_gather` -- the tiles are small -- and keeps doing so."""
-    global _GATHER_OK
-    import torch
-    import torch.distributed as dist
-
-    if _GATHER_OK:
-        try:
-            parts = [torch.empty_like(tile) for _ in range(world)] if rank == dst else None
-            dist.gather(tile, gather_list=parts, dst=dst, group=group)
-            return parts
-        except (RuntimeError, NotImplementedError):
-            _GATHER_OK = False
-    parts = [torch.empty_like(tile) for _ in range(world)]
-    dist.all_gather(parts, tile, group=group)
-    return parts if rank == dst else None
+    return img.clone(), ang.clone()

@@ -259,6 +259,23 @@ def regrid_beam(p: Problem, nx=None, ny=None, na=None, nb=None, a_centre=None, b
     return q
 
 
+def regrid_seed_beam(p: Problem, nx=None, ny=None, na=None, nb=None) -> Problem:
+    """The same cell-centred regrid for the seed beam (the ray grid of the seeded mode)."""
+    q = copy.copy(p)
+    s = copy.copy(p.seed_beam)
+    for ax, dn, n in (("x", "dx", nx), ("y", "dy", ny), ("a", "da", na), ("b", "db", nb)):
+        if n is None:
+            continue
+        g, d = getattr(p.seed_beam, ax), getattr(p.seed_beam, dn)
+        lo, hi = g[0] - 0.5 * d, g[-1] + 0.5 * d
+        nd = (hi - lo) / n
+        setattr(s, dn, nd)
+        setattr(s, ax, _f64(lo + (0.5 + np.arange(n)) * nd))
+    q.seed_beam = s
+    q.golden_image = q.golden_I_ang = None
+    return q
+
+
 def resample_frequency(p: Problem, nv: int) -> Problem:
     """Linear resampling of the frequency axis of every gain table (gv rows)
     and of dv, preserving sum(dv) -- the synthetic nv=512 workload of

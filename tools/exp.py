@@ -1,0 +1,60 @@
+"""Kernel experiment driver: best-of timings of the two kernels on the stock workloads for one or more
+builds of the library, optionally with the bit-for-bit march-record check against the oracle.
+
+  python tools/exp.py [--check] [--cases ase,seed] [lib.so ...]     (default: csrc/librt_hip.so)
+"""
+import importlib, sys, time
+sys.path.insert(0, '.')
+import numpy as np
+rt = importlib.import_module("raytrace-miniapp_amd")
+be = importlib.import_module("raytrace-miniapp_amd.backend")
+
+args = sys.argv[1:]
+check = "--check" in args
+cases = "ase,seed"
+if "--cases" in args:
+    cases = args[args.index("--cases") + 1]
+libs = [a for a in args if a.endswith(".so")] or [str(be.CSRC / "librt_hip.so")]
+base = rt.datfile.load('tests/golden/ASE_small.dat.xz')
+probs = {"ase": rt.scale_problem(base, 16.0), "seed": rt.datfile.load('tests/golden/seed_small.dat.xz'),
+         "small": base}
+for case in cases.split(","):
+    p = probs[case]
+    plans = []
+    for path in libs:
+        plan = be.Plan(p, lib=be.HipLibrary(path))
+        plan.set_ray_grid()
+        plans.append(plan)
+    best = [(1e9, 1e9)] * len(libs)
+    for rnd in range(5):
+        for i, plan in enumerate(plans):
+            for _ in range(2):
+                plan.run()
+                st = plan.fetch(want_image=False)["stats"]
+                best[i] = (min(best[i][0], st["march_ms"]), min(best[i][1], st["freq_ms"]))
+    for path, b in zip(libs, best):
+        print(f"{case:5s} {path.split('/')[-1]:34s} march {b[0]:7.3f} ms  freq {b[1]:7.3f} ms  sum {b[0]+b[1]:7.3f}", flush=True)
+    for plan in plans:
+        plan.close()
+    if check:
+        from oracle.binding import Oracle
+        rays = p.build_rays()
+        with be.Plan(p, lib=be.HipLibrary(libs[0])) as plan:
+            plan.set_ray_grid().enable_probe().run()
+            out = plan.fetch()
+            pr = plan.fetch_probe()
+        ora = Oracle()
+        n = len(rays)
+        bad = 0
+        t0 = time.time()
+        for a in range(0, n, 800000):
+            b = min(n, a + 800000)
+            o = ora.probe(p, rays[a:b], want_Iv=False)
+            for key in ("gvl", "evl"):
+                bad += int((pr[key][a:b].view(np.uint32) != o[key].view(np.uint32)).any(axis=1).sum())
+            bad += int((pr["ivl"][a:b] != o["ivl"]).any(axis=1).sum()) + int((pr["steps"][a:b] != o["steps"]).sum())
+            bad += int(((pr["flags"][a:b] & 3) != (o["flags"] & 3)).sum())
+            okm = o["err"] == 0
+            for key in "xyab":
+                bad += int((pr["ray2"][key][a:b][okm].view(np.uint32) != o["ray2"][key][okm].view(np.uint32)).sum())
+        print(f"{case:5s} record check: rays {n}, mismatching records/fields {bad}, oracle {time.time()-t0:.1f} s", flush=True)
