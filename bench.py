@@ -312,11 +312,20 @@ def main() -> int:
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     scaling = args.scaling or ("strong" if world > 1 else "weak")
+    # Rehearsal on a box with fewer GPUs than ranks (never a measurement): RT_BENCH_BACKEND=gloo stages the
+    # collectives through host memory, RT_BENCH_SHARE_GPU=1 puts every rank on device 0.
+    dist_backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if os.environ.get("RT_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if dist_backend == "nccl" else torch.device("cpu")  # where the bookkeeping all-reduces live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(dist_backend)
 
     full, data = build_workload(rt, problem_mod, args.workload, world, scaling)
     mine = multigpu.shard(full, rank, world)
@@ -326,7 +335,7 @@ def main() -> int:
     plan.set_ray_grid()
     n_ang = b.na * b.nb
     # one buffer per rank, (tile | I_ang): the assembly is ONE collective
-    asm = multigpu.Assembler(full, rank, world, dev)
+    asm = multigpu.Assembler(full, rank, world, dev, via_host=(dist_backend != "nccl"))
     image, iang = asm.image, asm.iang
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -356,9 +365,9 @@ def main() -> int:
     stats = st["stats"]
     march_ms = float(np.mean([k[0] for k in kms]))
     freq_ms = float(np.mean([k[1] for k in kms]))
-    t = torch.tensor([dt, march_ms + freq_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, march_ms + freq_ms], dtype=torch.float64, device=cdev)
     cnt = torch.tensor([float(stats["cell_steps"]), float(stats["n_rays"]), float(stats["n_rays"] - stats["n_escaped"])],
-                       dtype=torch.float64, device=dev)
+                       dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)

@@ -101,7 +101,8 @@ class Assembler:
       seeded : a sum-reduce of the buffers (full image | I_ang) to rank dst.
     Backend "nccl" is RCCL on ROCm; the CPU tests run the same code over gloo."""
 
-    def __init__(self, problem: Problem, rank: int, world: int, device=None, group=None, dst: int = 0):
+    def __init__(self, problem: Problem, rank: int, world: int, device=None, group=None, dst: int = 0,
+                 via_host: bool = False):
         import torch
 
         b = problem.beam
@@ -116,9 +117,13 @@ class Assembler:
         self.buffer = torch.zeros(self.n_tile_max + self.n_ang, dtype=torch.float64, device=dev)
         self.image = self.buffer[:self.n_tile]
         self.iang = self.buffer[self.n_tile_max:]
+        # via_host: device buffers, collectives on host copies (rehearsal of the N-rank path over gloo on a
+        # box whose ranks share one GPU; RCCL takes the device buffers directly)
+        self.via_host = via_host and dev.type != "cpu"
+        cdev = torch.device("cpu") if self.via_host else dev
         self.recv = None
         if world > 1 and not self.seeded and rank == dst:
-            self.recv = torch.empty((world, self.n_tile_max + self.n_ang), dtype=torch.float64, device=dev)
+            self.recv = torch.empty((world, self.n_tile_max + self.n_ang), dtype=torch.float64, device=cdev)
 
     def describe(self) -> str:
         n = (self.n_tile_max + self.n_ang) * 8
@@ -136,6 +141,8 @@ class Assembler:
         b = self.problem.beam
         if self.world == 1:
             return buf[:self.n_tile], buf[self.n_tile_max:]
+        if self.via_host:
+            buf = buf.cpu()
         if self.seeded:
             dist.reduce(buf, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group)
             return (buf[:self.n_tile], buf[self.n_tile_max:]) if self.rank == self.dst else (None, None)

@@ -56,5 +56,14 @@ def oracle():
 def hip():
     """The product library; GPU tests fail loudly if it is not built."""
     from importlib import import_module
+    # Tests that hand torch device buffers to the plan need ONE HIP runtime in the process: torch brings
+    # its own copy of libamdhip64, and whichever is loaded first serves both (bench.py loads torch first
+    # for the same reason).  So torch goes first here too.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     backend = import_module("raytrace-miniapp_amd.backend")
     return backend
