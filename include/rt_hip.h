@@ -119,11 +119,59 @@ int rt_hip_selftest(int device, unsigned long long *n_checked, unsigned long lon
  *          RayTraceImageCPU.cpp:32-36); failed_rays receives at most
  *          max_failed rays, *n_failed the number stored.
  *   stats may be NULL.
+ * A ray list that is the full tensor grid of four 1-D grids in create_image's order
+ * (src/RayTraceImage.cpp:300-328) is recognised: the rays are then generated on the device
+ * (rt_hip_plan_set_ray_grid) while host threads verify the list ray by ray, bit for bit; should the
+ * verification fail the result is discarded and the list itself is uploaded and traced.  Lists of
+ * 2^32 - 512 rays or more are rejected (RT_ERR_ARG): the kernels index rays with 32 bits.
+ * If failure_code comes back non-zero, image and I_ang hold exactly what RayTraceImageCPULoop leaves:
+ * the failing rays deposit nothing (RayTraceImageCPU.cpp:29-36) -- the frequency pass is repeated in a
+ * checking mode for such a run.
  */
 int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gain,
                       const rt_seed *seed, int method, const rt_ray *rays, size_t n_rays,
                       double scale, double *image, double *I_ang, unsigned int *failure_code,
                       rt_ray *failed_rays, int max_failed, int *n_failed, rt_stats *stats);
+
+/*
+ * All devices of the node in one call: what RayTraceImageHipMultiGPULoop calls.  Replaces the
+ * "cuda-multigpu" arm of the dispatcher (src/RayTraceImage.cpp:389-405), which runs
+ * RayTraceImageThreadLoop (:89-134: contiguous ray chunks, one host thread and one private full image
+ * per device, images added on the host at join) and, for the assembly, stands where a multi-rank run
+ * of the application uses MPI (src/MPI_helpers.h:29-38, intensity_step_struct::sum_reduce).
+ *   One process, one host thread per device, the device bound INSIDE the worker (the reference binds it
+ *   in the spawning thread, RayTraceImage.cpp:116), one RCCL communicator over the ndev devices
+ *   (ncclCommInitAll, kept across calls like the queues; librccl is loaded on first use).
+ *   ASE (method 1, no seed) with `rays` = the full tensor grid of the beam (recognised from the list
+ *   itself and verified ray by ray): pixel-column tiles -- device d traces image columns d, d+ndev, ...
+ *   from a ray grid generated on the device and holds a compact tile [ny][nx_d][nv]; the tiles and the
+ *   I_ang partial sums travel to device 0 in ONE grouped ncclSend/ncclRecv gather (every peer over its
+ *   own xGMI link), one kernel interleaves the columns and adds the I_ang parts, one download.
+ *   Anything else (seeded mode, arbitrary ray lists): contiguous ray chunks, a full image per device,
+ *   ncclReduce(sum, f64) to device 0, one download.
+ * ndev <= 0: all devices.  ndev = 1 is a degenerate communicator (self send/recv) and gives the image of
+ * rt_hip_image_loop.  Same outputs and error convention as rt_hip_image_loop; stats: counters summed,
+ * times = maximum over devices, total_ms = wall time of the call.
+ */
+int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain *gain, const rt_seed *seed,
+                            int method, const rt_ray *rays, size_t n_rays, double scale, double *image,
+                            double *I_ang, unsigned int *failure_code, rt_ray *failed_rays, int max_failed,
+                            int *n_failed, rt_stats *stats);
+
+/* Host-only helper (no device needed): 1 if the list is exactly the tensor grid of four 1-D grids in
+ * create_image's order (b fastest, then a, y, x; src/RayTraceImage.cpp:300-328) -- every ray compared
+ * bit for bit -- with dims = {nx, ny, na, nb}; 0 otherwise.  This is the test the two entry points
+ * above apply before they generate the rays on the device. */
+int rt_hip_ray_list_grid_dims(const rt_ray *rays, size_t n_rays, int dims[4]);
+
+/* How the last rt_hip_multi_image_loop of this thread was partitioned: 1 = pixel-column tiles + gather,
+ * 2 = ray chunks + sum-reduce, 0 = none yet.  (Diagnostics and tests.) */
+int rt_hip_multi_last_mode(void);
+
+/* Device allocations -- never data -- are kept across calls (ray lists, tangents, march records;
+ * Readme.txt:43 forbids caching data only).  This returns every parked block of every device to the
+ * driver; RT_HIP_POOL_MAX_MB in the environment caps what may be parked (default 32768). */
+void rt_hip_pool_trim(void);
 
 /*
  * Device-resident plan: the same path with inputs already in HBM, so that a

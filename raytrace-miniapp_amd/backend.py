@@ -254,14 +254,48 @@ def image_loop(problem: Problem, rays: np.ndarray | None = None, device: int = 0
                 stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_})
 
 
+def multi_image_loop(problem: Problem, rays: np.ndarray | None = None, n_devices: int = 0) -> dict:
+    """RayTraceImageHipMultiGPULoop through rt_hip_multi_image_loop: all devices of the node, one RCCL
+    collective per image (include/rt_hip.h).  n_devices <= 0: every device.  Returns what image_loop
+    returns plus `mode` (1 = pixel-column tiles + gather, 2 = ray chunks + sum-reduce)."""
+    hl = HipLibrary.get()
+    m = cabi.Marshalled(problem)
+    if rays is None:
+        rays = problem.build_rays()
+    rays = np.ascontiguousarray(rays, dtype=cabi.RAY_DTYPE)
+    b = problem.beam
+    image = np.zeros(b.nx * b.ny * b.nv)
+    iang = np.zeros(b.na * b.nb)
+    code = C.c_uint(0)
+    nf = C.c_int(0)
+    failed = np.zeros(cabi.RT_N_FAILED_MAX, dtype=cabi.RAY_DTYPE)
+    st = cabi.RtStats()
+    rc = hl.lib.rt_hip_multi_image_loop(n_devices, m.N, C.byref(m.beam), m.gain, m.seed_ref, problem.method,
+                                        cabi.rays_ptr(rays), len(rays), problem.scale, cabi._dp(image),
+                                        cabi._dp(iang), C.byref(code), cabi.rays_ptr(failed),
+                                        cabi.RT_N_FAILED_MAX, C.byref(nf), C.byref(st))
+    hl.check(rc, "rt_hip_multi_image_loop")
+    return dict(image=image, I_ang=iang, failure_code=code.value, failed_rays=failed[:nf.value].copy(),
+                stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_}, mode=int(hl.lib.rt_hip_multi_last_mode()))
+
+
+def ray_list_grid_dims(rays: np.ndarray):
+    """(nx, ny, na, nb) if the list is a whole tensor grid in create_image's order, else None (host only)."""
+    hl = HipLibrary.get()
+    rays = np.ascontiguousarray(rays, dtype=cabi.RAY_DTYPE)
+    dims = (C.c_int * 4)()
+    ok = hl.lib.rt_hip_ray_list_grid_dims(cabi.rays_ptr(rays), len(rays), C.byref(dims))
+    return tuple(dims) if ok else None
+
+
 _FAILURE_TEXT = {1: "Invalid ray detected", 2: "Negitive intensity detected", 3: "NaNs detected in intensity"}
 
 
 def create_image(problem: Problem, method: str = "auto", device: int = 0, device_rays: bool = True) -> dict:
     """Mirror of RayTrace::create_image (src/RayTraceImage.cpp:227-434) with the
     arms this backend adds: "hip" (one device) and "hip-multigpu" (all devices of
-    the node, rays split in contiguous chunks as RayTraceImageThreadLoop does,
-    partial images summed).  "auto" resolves to "hip".  Any other method string
+    the node behind rt_hip_multi_image_loop: pixel-column tiles + RCCL gather for
+    ASE, ray chunks + RCCL sum-reduce otherwise).  "auto" resolves to "hip".  Any other method string
     is an error -- the CPU/OpenMP/CUDA arms belong to the reference.
 
     Returns dict(image [ny][nx][nv] flat, I_ang, stats)."""
@@ -277,8 +311,7 @@ def create_image(problem: Problem, method: str = "auto", device: int = 0, device
                 plan.set_rays(problem.build_rays())
             out = plan.run().fetch()
     elif m == "hip-multigpu":
-        from .multigpu import thread_loop
-        out = thread_loop(problem)
+        out = multi_image_loop(problem)
     else:
         raise RayTraceError("Unknown method: " + m)
     if out["failure_code"] != 0:

@@ -6,18 +6,25 @@
 // table into ONE arena, uploads it with ONE copy, zeroes outputs + control block
 // and launches the march kernel and the frequency kernel back to back on one
 // stream.  No data is cached across calls (Readme.txt:43); freed device allocations and one
-// queue per device are (the pool and loop_queue below).
+// queues per device are (the pool and lease_queue below).
 #include "rt_path.hip" // debug path tracer (before rt_freq.hip: no FMA contraction there)
 #include "rt_freq.hip" // kernel B (includes rt_march.hip, kernel A)
 
+#include <rccl/rccl.h> // types and prototypes only: librccl.so is loaded on first use (rccl_api below)
+
+#include <dlfcn.h>
+
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cfloat>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -72,8 +79,20 @@ struct ArenaBuilder {
 // call and hipMalloc/hipFree of them costs milliseconds.  Freed blocks are parked per device
 // (at most POOL_MAX_BLOCKS, POOL_MAX_BYTES) and handed out again best-fit.
 constexpr size_t POOL_MAX_BLOCKS = 8;
-constexpr size_t POOL_MAX_BYTES  = (size_t) 32 << 30;
 constexpr size_t POOL_MIN_BYTES  = (size_t) 1 << 20; // small blocks are not worth parking
+size_t pool_max_bytes()
+{
+    static const size_t cap = [] {
+        size_t mb = 32768;
+        if (const char *e = getenv("RT_HIP_POOL_MAX_MB")) {
+            const long long v = atoll(e);
+            if (v >= 0)
+                mb = (size_t) v;
+        }
+        return mb << 20;
+    }();
+    return cap;
+}
 struct PoolBlock {
     int device;
     void *ptr;
@@ -104,13 +123,19 @@ hipError_t pool_alloc(int device, void **out, size_t bytes)
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) { // out of memory: drop the parked blocks and retry once
+        (void) hipGetLastError();
+        int cur = device;
+        (void) hipGetDevice(&cur);
         std::vector<PoolBlock> drop;
         {
             std::lock_guard<std::mutex> lk(g_pool_mutex);
             drop.swap(g_pool);
         }
-        for (auto &b : drop)
+        for (auto &b : drop) {
+            (void) hipSetDevice(b.device);
             (void) hipFree(b.ptr);
+        }
+        (void) hipSetDevice(cur);
         e = hipMalloc(out, bytes);
     }
     if (e == hipSuccess) {
@@ -118,6 +143,48 @@ hipError_t pool_alloc(int device, void **out, size_t bytes)
         g_pool_sizes[*out] = bytes;
     }
     return e;
+}
+
+void pool_trim_all()
+{
+    std::vector<PoolBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        drop.swap(g_pool);
+    }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto &b : drop) {
+        (void) hipSetDevice(b.device);
+        (void) hipFree(b.ptr);
+    }
+    if (have)
+        (void) hipSetDevice(cur);
+}
+
+// hipMalloc for the large one-off allocations (arena, own image, path, probe): out of memory
+// while the pool still parks blocks -> give them back and retry once
+hipError_t dev_malloc(void **out, size_t bytes)
+{
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        pool_trim_all();
+        e = hipMalloc(out, bytes ? bytes : 16);
+    }
+    return e;
+}
+
+// tuning overrides from the environment: a missing, non-numeric or non-positive value keeps the default
+unsigned env_unsigned(const char *name, unsigned def, unsigned lo, unsigned hi)
+{
+    const char *e = getenv(name);
+    if (!e)
+        return def;
+    const long v = atol(e);
+    if (v <= 0)
+        return def;
+    return (unsigned) (v < (long) lo ? lo : (v > (long) hi ? hi : v));
 }
 
 void pool_free(int device, void *ptr)
@@ -135,7 +202,7 @@ void pool_free(int device, void *ptr)
         size_t held = 0;
         for (auto &b : g_pool)
             held += b.bytes;
-        if (bytes >= POOL_MIN_BYTES && g_pool.size() < POOL_MAX_BLOCKS && held + bytes <= POOL_MAX_BYTES) {
+        if (bytes >= POOL_MIN_BYTES && g_pool.size() < POOL_MAX_BLOCKS && held + bytes <= pool_max_bytes()) {
             g_pool.push_back({ device, ptr, bytes });
             return;
         }
@@ -213,8 +280,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     // (surplus work-groups find the tile counter exhausted and leave)
     int per_cu = (int) ((160 * 1024) / (lds + lds_stat + 512));
     per_cu     = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-    if (const char *e = getenv("RT_HIP_FREQ_WGS")) // tuning override
-        per_cu = atoi(e);
+    per_cu = (int) env_unsigned("RT_HIP_FREQ_WGS", (unsigned) per_cu, 1, 16); // tuning override
     unsigned long long want = ((unsigned long long) p->P.n_tiles + 3) / 4;
     unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
     if (cap_blocks && cap > cap_blocks)
@@ -227,20 +293,46 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     return RT_OK;
 }
 
-// One non-blocking queue per device for rt_hip_image_loop, kept across calls like the memory
-// pool (a resource, not data): synchronous copies on the host thread do not wait for it, which
-// is what lets the ray upload overlap the march.  Creating a queue costs ~2 ms: once.
-static hipStream_t loop_queue(int device)
+// Non-blocking queues for the host-pointer entry points, kept across calls like the memory pool
+// (a resource, not data; creating one costs ~2 ms): synchronous copies on the host thread do not
+// wait for them, which is what lets the ray upload overlap the march.  Every call LEASES a queue
+// of its device for its own use, so concurrent calls on one device (create_image is thread-safe,
+// RayTrace.h:90-91) neither share a stream nor see each other's kernels in their event times.
+static std::mutex g_queue_mutex;
+static std::vector<hipStream_t> g_queue_free[64];
+static hipStream_t lease_queue(int device)
 {
-    static std::mutex mu;
-    static hipStream_t q[64] = {};
-    std::lock_guard<std::mutex> lock(mu);
     if (device < 0 || device >= 64)
         return nullptr;
-    if (!q[device] && hipSetDevice(device) == hipSuccess &&
-        hipStreamCreateWithFlags(&q[device], hipStreamNonBlocking) != hipSuccess)
-        q[device] = nullptr;
-    return q[device];
+    {
+        std::lock_guard<std::mutex> lock(g_queue_mutex);
+        if (!g_queue_free[device].empty()) {
+            hipStream_t q = g_queue_free[device].back();
+            g_queue_free[device].pop_back();
+            return q;
+        }
+    }
+    hipStream_t q = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
+        return nullptr;
+    return q;
+}
+static void release_queue(int device, hipStream_t q)
+{
+    if (!q || device < 0 || device >= 64)
+        return;
+    std::lock_guard<std::mutex> lock(g_queue_mutex);
+    g_queue_free[device].push_back(q);
+}
+
+// Wait for the work of the plan's last run before any of its buffers is freed or parked in the pool:
+// another plan may be handed a parked block at once (pool_alloc) and overwrite it.
+static void plan_quiesce(rt_hip_plan *p)
+{
+    if (p && p->ran) {
+        if (hipStreamSynchronize(p->last_stream) != hipSuccess)
+            (void) hipGetLastError(); // a caller's stream that is gone: nothing is in flight on it
+    }
 }
 
 // Two-kernel path: march (persistent lanes) -> records in HBM -> frequency pass.
@@ -248,6 +340,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
 {
     const size_t need = (size_t) p->n_rays * p->P.rec_stride;
     if (need > p->rec_bytes || !p->rec) {
+        plan_quiesce(p);
         pool_free(p->device, p->rec);
         p->rec = nullptr;
         HIP_TRY(pool_alloc(p->device, (void **) &p->rec, need ? need : 16));
@@ -268,8 +361,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         const unsigned long long per_cu_rays = p->cu_count ? p->n_rays / (unsigned long long) p->cu_count : 0;
         bthr = per_cu_rays >= 3ull * 1024 ? 1024u : (per_cu_rays >= 3ull * 768 ? 768u : 512u);
     }
-    if (const char *e = getenv("RT_HIP_MARCH_THREADS")) // occupancy experiments
-        bthr = (unsigned) atoi(e);
+    bthr = env_unsigned("RT_HIP_MARCH_THREADS", bthr, 64, lds_tab ? 1024 : 256) / 64 * 64; // occupancy experiments
     const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
     int per_cu          = 0;
     if (lds_tab) {
@@ -289,8 +381,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
     ch                    = ch < 16 ? 16 : (ch > 512 ? 512 : ch);
     p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
-    if (const char *e = getenv("RT_HIP_MARCH_CHUNK")) // tuning
-        p->P.chunk = (unsigned) atoi(e);
+    p->P.chunk = env_unsigned("RT_HIP_MARCH_CHUNK", p->P.chunk, 1, 1u << 20); // tuning
     p->P.path_on = p->path_on ? 1u : 0u;
     if (p->path_on) {
         const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
@@ -299,7 +390,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
             (void) hipFree(p->path_err);
             p->path_dev = nullptr;
             p->path_err = nullptr;
-            HIP_TRY(hipMalloc((void **) &p->path_dev, (size_t) p->n_rays * n2 * 3 * sizeof(float) + 16));
+            HIP_TRY(dev_malloc((void **) &p->path_dev, (size_t) p->n_rays * n2 * 3 * sizeof(float) + 16));
             HIP_TRY(hipMalloc((void **) &p->path_err, (size_t) p->n_rays * sizeof(int32_t) + 16));
             p->path_rays = (size_t) p->n_rays;
         }
@@ -315,8 +406,8 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     // the march of a slice runs on image_loop's non-blocking queue while the host copies the next
     // one (16 B/ray: 102 MB, ~3 ms for the 6.4 M-ray case; swept: 3 slices 5.8 ms, 1 slice 6.9, 8 slices 7.3).
     unsigned n_launch = (p->host_rays && p->n_rays >= (2ull << 20)) ? 3u : 1u;
-    if (const char *e = getenv("RT_HIP_UPLOAD_SLICES")) // tuning
-        n_launch = p->host_rays ? (unsigned) atoi(e) : 1u;
+    if (p->host_rays)
+        n_launch = env_unsigned("RT_HIP_UPLOAD_SLICES", n_launch, 1, 8); // tuning
     n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
     for (unsigned c = 0; c < n_launch && grid > 0 && !(p->P.debug & 2u); c++) {
         const unsigned long long b = p->n_rays * c / n_launch, e = p->n_rays * (c + 1) / n_launch;
@@ -401,6 +492,7 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
     if (!p)
         return;
     (void) hipSetDevice(p->device);
+    plan_quiesce(p); // kernels of an unfetched (or failed) run may still use the buffers parked below
     if (p->ev0)
         (void) hipEventDestroy(p->ev0);
     if (p->ev1)
@@ -585,7 +677,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     } while (0)
 
     p->arena_bytes = align_up(ab.host.size(), 256);
-    PLAN_TRY(hipMalloc((void **) &p->arena, p->arena_bytes));
+    PLAN_TRY(dev_malloc((void **) &p->arena, p->arena_bytes));
     unsigned char *A = p->arena;
     for (int i = 1; i < N; i++) {
         dg[(size_t) i].gv = reinterpret_cast<const float *>(A + off_gv[(size_t) i]);
@@ -673,9 +765,15 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
 
 // rt_hip_image_loop only: the list stays on the host until the run, which uploads it in slices
 // beside the march (the caller's buffer outlives the call, the plan does not)
+// the kernels index rays with 32 bits, and the march reserves up to 512 indices past the end
+constexpr size_t MAX_LIST_RAYS = 0xffffffffull - 512;
+
 static int plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
 {
+    if (n_rays > MAX_LIST_RAYS)
+        return fail_arg("ray list of 2^32 - 512 rays or more: split the call");
     HIP_TRY(hipSetDevice(p->device));
+    plan_quiesce(p);
     pool_free(p->device, p->rays_dev);
     pool_free(p->device, p->tan_dev);
     p->rays_dev = nullptr;
@@ -698,7 +796,10 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
 {
     if (!p || (n_rays && !rays))
         return fail_arg("rt_hip_plan_set_rays: NULL argument");
+    if (n_rays > MAX_LIST_RAYS)
+        return fail_arg("rt_hip_plan_set_rays: 2^32 - 512 rays or more: split the call");
     HIP_TRY(hipSetDevice(p->device));
+    plan_quiesce(p);
     pool_free(p->device, p->rays_dev);
     p->rays_dev = nullptr;
     if (n_rays) {
@@ -738,6 +839,7 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     if (first < 0 || stride < 1 || count < 0 || (count > 0 && first + (count - 1) * stride >= total))
         return fail_arg("rt_hip_plan_set_ray_grid: ray range outside the grid");
     HIP_TRY(hipSetDevice(p->device));
+    plan_quiesce(p);
     (void) hipFree(p->grid_dev);
     p->grid_dev     = nullptr;
     (void) hipFree(p->seedtab_dev);
@@ -780,7 +882,7 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     R.count        = (unsigned long long) count;
     p->n_rays      = (unsigned long long) count;
     if (p->P.has_seed && p->P.method != 1) {
-        HIP_TRY(hipMalloc((void **) &p->seedtab_dev, nn * sizeof(double) + nn));
+        HIP_TRY(dev_malloc((void **) &p->seedtab_dev, nn * sizeof(double) + nn));
         unsigned char *flags = reinterpret_cast<unsigned char *>(p->seedtab_dev + nn);
         hipLaunchKernelGGL(rt::rt_seed_tab_kernel, dim3((unsigned) ((nn + 255) / 256)), dim3(256), 0, nullptr, p->P.seed,
                            R, p->seedtab_dev, flags);
@@ -792,8 +894,16 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     // One ray per pixel, every pixel covered: in ASE mode ray ijkm lands in pixel (i, j)
     // (SURVEY.md 8(c) i) -- the deposit index of the ray is verified per ray by the kernel,
     // which falls back to atomics for any ray that does not land in its own pixel.
+    // (as the floats a ray carries: a list recognised as a grid, rt_hip_image_loop, arrives as floats)
     auto same = [](const std::vector<double> &v, const double *g, int n) {
-        return (int) v.size() == n && memcmp(v.data(), g, sizeof(double) * (size_t) n) == 0;
+        if ((int) v.size() != n)
+            return false;
+        for (int i = 0; i < n; i++) {
+            const float a = (float) v[(size_t) i], b = (float) g[i];
+            if (memcmp(&a, &b, sizeof(float)) != 0)
+                return false;
+        }
+        return true;
     };
     // RayTraceImageCPU.cpp:11-16 on the host: grid point i (rounded to float, as the ray
     // carries it) must fall in deposit cell i
@@ -905,7 +1015,7 @@ static int plan_prepare_probe(rt_hip_plan *p)
         (void) hipFree(p->probe);
         p->probe = nullptr;
         size_t bytes = n * (sizeof(rt_ray) + 8) + 1024;
-        HIP_TRY(hipMalloc((void **) &p->probe, bytes));
+        HIP_TRY(dev_malloc((void **) &p->probe, bytes));
         p->probe_rays = n;
     }
     unsigned char *b = p->probe;
@@ -926,12 +1036,12 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (!image_dev) {
         if (!p->image_own)
-            HIP_TRY(hipMalloc((void **) &p->image_own, p->n_image * sizeof(double)));
+            HIP_TRY(dev_malloc((void **) &p->image_own, p->n_image * sizeof(double)));
         image_dev = p->image_own;
     }
     if (!iang_dev) {
         if (!p->iang_own)
-            HIP_TRY(hipMalloc((void **) &p->iang_own, p->n_iang * sizeof(double)));
+            HIP_TRY(dev_malloc((void **) &p->iang_own, p->n_iang * sizeof(double)));
         iang_dev = p->iang_own;
     }
     int rc = plan_prepare_probe(p);
@@ -1068,6 +1178,102 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
     return RT_OK;
 }
 
+// ---- a ray list that is really a tensor grid ---------------------------------------------------
+// RayTrace::create_image builds its list from four 1-D grids, b fastest, then a, y, x
+// (src/RayTraceImage.cpp:300-328), and hands the back-end loop only the list.  The grids are read back
+// from it in O(nx + ny + na + nb) -- the period of each coordinate -- and the whole list is then
+// compared with the grid ray by ray, bit for bit, on host threads.
+struct GridGuess {
+    std::vector<double> g[4]; // x, y, a, b as the doubles of the floats the rays carry
+};
+static inline bool same_bits(float a, float b) { return memcmp(&a, &b, sizeof(float)) == 0; }
+
+static bool guess_ray_grid(const rt_ray *rays, size_t n, GridGuess &G)
+{
+    if (n == 0)
+        return false;
+    // period of b: the first later ray whose b equals that of ray 0 (grid values are distinct)
+    size_t nb = 1;
+    while (nb < n && !same_bits(rays[nb].b, rays[0].b))
+        nb++;
+    size_t na = 1;
+    while (na * nb < n && !same_bits(rays[na * nb].a, rays[0].a))
+        na++;
+    size_t ny = 1;
+    while (ny * na * nb < n && !same_bits(rays[ny * na * nb].y, rays[0].y))
+        ny++;
+    const size_t block = nb * na * ny;
+    if (block == 0 || n % block != 0)
+        return false;
+    const size_t nx = n / block;
+    if (nx > 0x7fffffffull || ny > 0x7fffffffull || na > 0x7fffffffull || nb > 0x7fffffffull || n > 0x7fffffffull)
+        return false;
+    G.g[0].resize(nx);
+    G.g[1].resize(ny);
+    G.g[2].resize(na);
+    G.g[3].resize(nb);
+    for (size_t i = 0; i < nx; i++)
+        G.g[0][i] = (double) rays[i * block].x;
+    for (size_t j = 0; j < ny; j++)
+        G.g[1][j] = (double) rays[j * na * nb].y;
+    for (size_t k = 0; k < na; k++)
+        G.g[2][k] = (double) rays[k * nb].a;
+    for (size_t m = 0; m < nb; m++)
+        G.g[3][m] = (double) rays[m].b;
+    return true;
+}
+
+// every ray of the list against the grid, on up to `threads` host threads
+static bool verify_ray_grid(const rt_ray *rays, size_t n, const GridGuess &G, unsigned threads)
+{
+    const size_t nb = G.g[3].size(), na = G.g[2].size(), ny = G.g[1].size();
+    std::vector<float> fx(G.g[0].begin(), G.g[0].end()), fy(G.g[1].begin(), G.g[1].end());
+    std::vector<float> fa(G.g[2].begin(), G.g[2].end()), fb(G.g[3].begin(), G.g[3].end());
+    const size_t rows = n / nb; // runs of nb rays that differ only in b
+    threads           = threads < 1 ? 1 : threads;
+    if (rows < 4 * (size_t) threads)
+        threads = 1;
+    std::atomic<bool> ok(true);
+    auto work = [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1 && ok.load(std::memory_order_relaxed); r++) {
+            const size_t k = r % na, j = (r / na) % ny, i = r / (na * ny);
+            const rt_ray want = { fx[i], fy[j], fa[k], 0.0f };
+            const rt_ray *row = rays + r * nb;
+            bool good         = true;
+            for (size_t m = 0; m < nb; m++) {
+                rt_ray w = want;
+                w.b      = fb[m];
+                good &= memcmp(&row[m], &w, sizeof(rt_ray)) == 0;
+            }
+            if (!good)
+                ok.store(false, std::memory_order_relaxed);
+        }
+    };
+    if (threads == 1) {
+        work(0, rows);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < threads; t++)
+            th.emplace_back(work, rows * t / threads, rows * (t + 1) / threads);
+        for (auto &t : th)
+            t.join();
+    }
+    return ok.load();
+}
+
+static unsigned host_threads(unsigned cap)
+{
+    unsigned h = std::thread::hardware_concurrency();
+    h          = h ? h : 1;
+    return env_unsigned("RT_HIP_HOST_THREADS", h < cap ? h : cap, 1, 64);
+}
+
+static int plan_set_guessed_grid(rt_hip_plan *p, const GridGuess &G, int64_t first, int64_t count)
+{
+    return rt_hip_plan_set_ray_grid(p, G.g[0].data(), (int) G.g[0].size(), G.g[1].data(), (int) G.g[1].size(),
+                                    G.g[2].data(), (int) G.g[2].size(), G.g[3].data(), (int) G.g[3].size(), first, 1, count);
+}
+
 int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gain, const rt_seed *seed,
                       int method, const rt_ray *rays, size_t n_rays, double scale, double *image,
                       double *I_ang, unsigned int *failure_code, rt_ray *failed_rays, int max_failed,
@@ -1075,20 +1281,404 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
 {
     if (!image || !I_ang)
         return fail_arg("rt_hip_image_loop: NULL output");
+    if (!rays && n_rays)
+        return fail_arg("rt_hip_image_loop: NULL ray list");
+    if (n_rays > MAX_LIST_RAYS)
+        return fail_arg("rt_hip_image_loop: 2^32 - 512 rays or more: split the call");
     rt_hip_plan *p = nullptr;
     int rc         = rt_hip_plan_create(&p, device, N, beam, gain, seed, method, scale);
     if (rc != RT_OK)
         return rc;
-    if (!rays && n_rays)
-        rc = fail_arg("rt_hip_image_loop: NULL ray list");
-    else
+    hipStream_t q = lease_queue(device);
+    // A list that is a whole tensor grid (what create_image builds) is not uploaded: the device
+    // generates the rays while host threads check the list against the grid, ray by ray.
+    GridGuess G;
+    bool as_grid = n_rays >= (1u << 16) && !getenv("RT_HIP_NO_GRID_DETECT") && guess_ray_grid(rays, n_rays, G);
+    if (as_grid) {
+        rc = plan_set_guessed_grid(p, G, 0, (int64_t) n_rays);
+        if (rc == RT_OK)
+            rc = rt_hip_plan_run(p, q, nullptr, nullptr); // asynchronous
+        if (rc == RT_OK && !verify_ray_grid(rays, n_rays, G, host_threads(8))) {
+            as_grid = false; // not that grid after all: the speculative result is discarded below
+            plan_quiesce(p);
+        }
+    }
+    if (rc == RT_OK && !as_grid) {
         rc = plan_set_rays_deferred(p, rays, n_rays);
-    if (rc == RT_OK)
-        rc = rt_hip_plan_run(p, loop_queue(device), nullptr, nullptr);
+        if (rc == RT_OK)
+            rc = rt_hip_plan_run(p, q, nullptr, nullptr);
+    }
     if (rc == RT_OK)
         rc = rt_hip_plan_fetch(p, image, I_ang, failure_code, failed_rays, max_failed, n_failed, stats);
-    rt_hip_plan_destroy(p);
+    rt_hip_plan_destroy(p); // waits for whatever is still in flight
+    release_queue(device, q);
     return rc;
+}
+
+// ---- all devices of the node --------------------------------------------------------------------
+namespace {
+
+// librccl.so is half a gigabyte: it is loaded when the multi-device entry is first used, not with
+// this library
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart   = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd       = nullptr;
+    decltype(&ncclSend) Send               = nullptr;
+    decltype(&ncclRecv) Recv               = nullptr;
+    decltype(&ncclReduce) Reduce           = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char *n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle)
+                break;
+        }
+        if (!api.handle) {
+            api.error = std::string("librccl.so not found: ") + dlerror();
+            return;
+        }
+#define RCCL_SYM(field, name)                                                      \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, name));    \
+    if (!api.field)                                                                \
+        api.error = std::string("librccl.so lacks ") + name;
+        RCCL_SYM(CommInitAll, "ncclCommInitAll")
+        RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        RCCL_SYM(GroupStart, "ncclGroupStart")
+        RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        RCCL_SYM(Send, "ncclSend")
+        RCCL_SYM(Recv, "ncclRecv")
+        RCCL_SYM(Reduce, "ncclReduce")
+        RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    });
+    return &api;
+}
+
+// one communicator over devices 0 .. ndev-1, kept across calls (creating it costs ~0.1-1 s)
+std::mutex g_multi_mutex; // one multi-device call at a time per process
+std::vector<ncclComm_t> g_comms;
+thread_local int g_multi_mode = 0;
+
+int multi_comms(int ndev, std::string &err)
+{
+    RcclApi *R = rccl_api();
+    if (!R->error.empty()) {
+        err = R->error;
+        return RT_ERR_NO_DEVICE;
+    }
+    if ((int) g_comms.size() == ndev)
+        return RT_OK;
+    for (auto c : g_comms)
+        (void) R->CommDestroy(c);
+    g_comms.assign((size_t) ndev, nullptr);
+    std::vector<int> devs((size_t) ndev);
+    for (int d = 0; d < ndev; d++)
+        devs[(size_t) d] = d;
+    ncclResult_t r = R->CommInitAll(g_comms.data(), ndev, devs.data());
+    if (r != ncclSuccess) {
+        err = std::string("ncclCommInitAll: ") + R->GetErrorString(r);
+        g_comms.clear();
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+// all workers arrive, or nobody passes: keeps a failed worker from leaving the others in a collective
+struct Rendezvous {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, arrived = 0, phase = 0;
+    bool failed = false;
+    explicit Rendezvous(int n_) : n(n_) {}
+    bool arrive(bool ok) // returns true if every worker of this phase was ok
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        failed = failed || !ok;
+        const int my = phase;
+        if (++arrived == n) {
+            arrived = 0;
+            phase++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return phase != my; });
+        }
+        return !failed;
+    }
+};
+
+inline int tile_cols(int nx, int d, int ndev) { return d < nx ? (nx - d + ndev - 1) / ndev : 0; }
+
+} // namespace
+
+namespace rt {
+// device 0 after the gather: recv = [ndev][stride] with stride = n_tile_max + n_ang doubles, part r =
+// tile [ny][cols(r)][K] of image columns r, r + ndev, ... followed (at n_tile_max) by its I_ang sums
+extern "C" __global__ void __launch_bounds__(256) rt_interleave_kernel(const double *recv, unsigned long long stride, int ndev,
+                                                                      int nx, int ny, int K, unsigned long long n_tile_max,
+                                                                      int n_ang, double *image, double *iang)
+{
+    const unsigned long long n_img = (unsigned long long) nx * (unsigned long long) ny * (unsigned long long) K;
+    const unsigned long long step  = (unsigned long long) gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; t < n_img; t += step) {
+        const unsigned k   = (unsigned) (t % (unsigned) K);
+        const unsigned long long pix = t / (unsigned) K;
+        const unsigned i = (unsigned) (pix % (unsigned) nx), j = (unsigned) (pix / (unsigned) nx);
+        const unsigned r = i % (unsigned) ndev, c = i / (unsigned) ndev;
+        const unsigned cols = r < (unsigned) nx ? ((unsigned) nx - r + (unsigned) ndev - 1) / (unsigned) ndev : 0;
+        image[t] = recv[r * stride + ((unsigned long long) j * cols + c) * (unsigned) K + k];
+    }
+    for (unsigned long long t = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; t < (unsigned long long) n_ang; t += step) {
+        double v = 0.0;
+        for (int r = 0; r < ndev; r++)
+            v += recv[(unsigned long long) r * stride + n_tile_max + t];
+        iang[t] = v;
+    }
+}
+} // namespace rt
+
+int rt_hip_multi_last_mode(void) { return g_multi_mode; }
+
+int rt_hip_ray_list_grid_dims(const rt_ray *rays, size_t n_rays, int dims[4])
+{
+    GridGuess G;
+    if (!rays || !dims || !guess_ray_grid(rays, n_rays, G) || !verify_ray_grid(rays, n_rays, G, host_threads(8)))
+        return 0;
+    for (int i = 0; i < 4; i++)
+        dims[i] = (int) G.g[i].size();
+    return 1;
+}
+
+void rt_hip_pool_trim(void) { pool_trim_all(); }
+
+int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain *gain, const rt_seed *seed,
+                            int method, const rt_ray *rays, size_t n_rays, double scale, double *image,
+                            double *I_ang, unsigned int *failure_code, rt_ray *failed_rays, int max_failed,
+                            int *n_failed, rt_stats *stats)
+{
+    if (!beam || !gain || !image || !I_ang)
+        return fail_arg("rt_hip_multi_image_loop: NULL argument");
+    if (!rays && n_rays)
+        return fail_arg("rt_hip_multi_image_loop: NULL ray list");
+    const int have = rt_hip_device_count();
+    if (have < 1) {
+        g_last_error = "no HIP device";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (ndev <= 0 || ndev > have)
+        ndev = have;
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> serial(g_multi_mutex);
+    {
+        std::string err;
+        const int rc = multi_comms(ndev, err);
+        if (rc != RT_OK) {
+            g_last_error = "rt_hip_multi_image_loop: " + err;
+            return rc;
+        }
+    }
+    RcclApi *R = rccl_api();
+
+    // ---- how to partition ----------------------------------------------------------------------
+    GridGuess G;
+    const bool is_grid = n_rays >= 1 && !getenv("RT_HIP_NO_GRID_DETECT") && guess_ray_grid(rays, n_rays, G) &&
+                         verify_ray_grid(rays, n_rays, G, host_threads(16));
+    auto axis_is = [](const std::vector<double> &g, const double *b, int n) {
+        if ((int) g.size() != n)
+            return false;
+        for (int i = 0; i < n; i++)
+            if (!same_bits((float) g[(size_t) i], (float) b[i]))
+                return false;
+        return true;
+    };
+    // pixel tiles: ASE, and the rays are the beam's own grid -- every ray then deposits into the pixel
+    // column it starts in (SURVEY.md 8(c) i; the frequency kernel computes the deposit cell per ray anyway)
+    const bool tiles = method == 1 && !seed && is_grid && axis_is(G.g[0], beam->x, beam->nx) &&
+                       axis_is(G.g[1], beam->y, beam->ny) && axis_is(G.g[2], beam->a, beam->na) &&
+                       axis_is(G.g[3], beam->b, beam->nb) && !getenv("RT_HIP_MULTI_NO_TILES");
+    g_multi_mode = tiles ? 1 : 2;
+
+    const int nx = beam->nx, ny = beam->ny, K = beam->nv;
+    const size_t n_ang = (size_t) beam->na * (size_t) beam->nb;
+    const size_t n_img = (size_t) nx * (size_t) ny * (size_t) K;
+    const size_t n_tile_max = tiles ? (size_t) ny * (size_t) tile_cols(nx, 0, ndev) * (size_t) K : n_img;
+    const size_t stride     = n_tile_max + n_ang; // doubles every device contributes
+
+    struct Worker {
+        int rc = RT_OK;
+        std::string error;
+        unsigned code = 0;
+        rt_ray failed[RT_N_FAILED_MAX];
+        int n_failed = 0;
+        rt_stats st  = {};
+    };
+    std::vector<Worker> W((size_t) ndev);
+    Rendezvous meet(ndev);
+    double *recv0 = nullptr, *out0 = nullptr; // device 0: gathered parts / assembled (image | I_ang)
+
+    auto work = [&](int d) {
+        Worker &w       = W[(size_t) d];
+        rt_hip_plan *p  = nullptr;
+        double *buf     = nullptr;
+        hipStream_t q   = nullptr;
+        auto fail       = [&](int rc, const std::string &what) {
+            if (w.rc == RT_OK) {
+                w.rc    = rc;
+                w.error = what;
+            }
+        };
+        auto hip_ok = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess)
+                fail(RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+        // -- plan on this device (the device is bound here, inside the worker)
+        if (hip_ok(hipSetDevice(d), "hipSetDevice")) {
+            q = lease_queue(d);
+            if (!q)
+                fail(RT_ERR_HIP, "no queue");
+        }
+        std::vector<double> xd;
+        if (w.rc == RT_OK) {
+            int rc;
+            if (tiles) {
+                rt_beam bd = *beam;
+                for (int i = d; i < nx; i += ndev)
+                    xd.push_back(beam->x[i]);
+                bd.nx = (int) xd.size();
+                bd.x  = xd.data();
+                if (bd.nx == 0) { // more devices than columns: an empty tile
+                    xd.push_back(beam->x[0]);
+                    bd.nx = 1;
+                    bd.x  = xd.data();
+                }
+                rc = rt_hip_plan_create(&p, d, N, &bd, gain, seed, method, scale);
+                if (rc == RT_OK) {
+                    const int cols      = tile_cols(nx, d, ndev);
+                    const int64_t count = (int64_t) cols * ny * beam->na * beam->nb;
+                    rc = rt_hip_plan_set_ray_grid(p, xd.data(), (int) xd.size(), beam->y, ny, beam->a, beam->na, beam->b,
+                                                  beam->nb, 0, 1, count);
+                }
+            } else {
+                rc = rt_hip_plan_create(&p, d, N, beam, gain, seed, method, scale);
+                // contiguous ray chunks, as RayTraceImageThreadLoop splits them (RayTraceImage.cpp:107)
+                const size_t chunk = n_rays / (size_t) ndev + 1;
+                const size_t begin = std::min((size_t) d * chunk, n_rays);
+                const size_t count = std::min(chunk, n_rays - begin);
+                if (rc == RT_OK)
+                    rc = is_grid ? plan_set_guessed_grid(p, G, (int64_t) begin, (int64_t) count)
+                                 : rt_hip_plan_set_rays(p, count ? rays + begin : nullptr, count);
+            }
+            if (rc != RT_OK)
+                fail(rc, rt_hip_last_error());
+        }
+        if (w.rc == RT_OK) {
+            hip_ok(pool_alloc(d, (void **) &buf, stride * sizeof(double)), "device buffer");
+            if (w.rc == RT_OK && d == 0) {
+                if (tiles)
+                    hip_ok(pool_alloc(0, (void **) &recv0, (size_t) ndev * stride * sizeof(double)), "gather buffer");
+                hip_ok(pool_alloc(0, (void **) &out0, (n_img + n_ang) * sizeof(double)), "image buffer");
+            }
+        }
+        if (w.rc == RT_OK && tiles && stride > (size_t) p->n_image + n_ang) // padding of a narrower tile travels too
+            hip_ok(hipMemsetAsync(buf, 0, stride * sizeof(double), q), "hipMemsetAsync");
+        if (w.rc == RT_OK) {
+            const int rc = rt_hip_plan_run(p, q, buf, buf + n_tile_max);
+            if (rc != RT_OK)
+                fail(rc, rt_hip_last_error());
+        }
+        // -- the one collective of the image, on the queue the kernels ran on
+        if (meet.arrive(w.rc == RT_OK)) {
+            ncclResult_t r = ncclSuccess;
+            if (tiles) {
+                r = R->GroupStart();
+                if (r == ncclSuccess)
+                    r = R->Send(buf, stride, ncclDouble, 0, g_comms[(size_t) d], q);
+                for (int src = 0; d == 0 && src < ndev && r == ncclSuccess; src++)
+                    r = R->Recv(recv0 + (size_t) src * stride, stride, ncclDouble, src, g_comms[0], q);
+                const ncclResult_t e = R->GroupEnd();
+                r                    = r == ncclSuccess ? e : r;
+                if (r == ncclSuccess && d == 0) {
+                    const unsigned long long n_out = (unsigned long long) n_img;
+                    unsigned blocks = (unsigned) std::min<unsigned long long>((n_out + 255) / 256, 256ull * 64ull);
+                    blocks          = blocks ? blocks : 1;
+                    hipLaunchKernelGGL(rt::rt_interleave_kernel, dim3(blocks), dim3(256), 0, q, recv0, (unsigned long long) stride,
+                                       ndev, nx, ny, K, (unsigned long long) n_tile_max, (int) n_ang, out0, out0 + n_img);
+                    hip_ok(hipGetLastError(), "rt_interleave_kernel");
+                }
+            } else {
+                r = R->Reduce(buf, d == 0 ? out0 : nullptr, stride, ncclDouble, ncclSum, 0, g_comms[(size_t) d], q);
+            }
+            if (r != ncclSuccess)
+                fail(RT_ERR_HIP, std::string("RCCL: ") + R->GetErrorString(r));
+            if (w.rc == RT_OK)
+                hip_ok(hipStreamSynchronize(q), "hipStreamSynchronize");
+            if (w.rc == RT_OK && d == 0) {
+                hip_ok(hipMemcpy(image, out0, n_img * sizeof(double), hipMemcpyDeviceToHost), "download image");
+                hip_ok(hipMemcpy(I_ang, out0 + n_img, n_ang * sizeof(double), hipMemcpyDeviceToHost), "download I_ang");
+            }
+        }
+        if (w.rc == RT_OK) {
+            const int rc = rt_hip_plan_fetch(p, nullptr, nullptr, &w.code, w.failed, RT_N_FAILED_MAX, &w.n_failed, &w.st);
+            if (rc != RT_OK)
+                fail(rc, rt_hip_last_error());
+        }
+        // every worker is past the collective before any buffer of it goes back to the pool
+        meet.arrive(true);
+        rt_hip_plan_destroy(p);
+        (void) hipSetDevice(d);
+        if (q)
+            (void) hipStreamSynchronize(q);
+        pool_free(d, buf);
+        if (d == 0) {
+            pool_free(0, recv0);
+            pool_free(0, out0);
+        }
+        release_queue(d, q);
+    };
+    std::vector<std::thread> th;
+    for (int d = 0; d < ndev; d++)
+        th.emplace_back(work, d);
+    for (auto &t : th) // join EVERY worker, then report the first error
+        t.join();
+    for (int d = 0; d < ndev; d++)
+        if (W[(size_t) d].rc != RT_OK) {
+            g_last_error = "device " + std::to_string(d) + ": " + W[(size_t) d].error;
+            return W[(size_t) d].rc;
+        }
+    unsigned code = 0;
+    int nf        = 0;
+    rt_stats tot  = {};
+    for (int d = 0; d < ndev; d++) {
+        const Worker &w = W[(size_t) d];
+        code |= w.code;
+        for (int i = 0; i < w.n_failed && failed_rays && nf < max_failed && nf < RT_N_FAILED_MAX; i++)
+            failed_rays[nf++] = w.failed[i];
+        tot.n_rays += w.st.n_rays;
+        tot.cell_steps += w.st.cell_steps;
+        tot.n_escaped += w.st.n_escaped;
+        tot.n_skipped += w.st.n_skipped;
+        tot.kernel_ms = std::max(tot.kernel_ms, w.st.kernel_ms);
+        tot.march_ms  = std::max(tot.march_ms, w.st.march_ms);
+        tot.freq_ms   = std::max(tot.freq_ms, w.st.freq_ms);
+    }
+    tot.total_ms = (float) std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (failure_code)
+        *failure_code = code;
+    if (n_failed)
+        *n_failed = nf;
+    if (stats)
+        *stats = tot;
+    return RT_OK;
 }
 
 } // extern "C"

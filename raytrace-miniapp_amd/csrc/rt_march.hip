@@ -494,7 +494,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 m.sx          = sx;
                 m.sy          = sy;
                 m.sz          = sz;
-                m.flags_steps = fl | ((unsigned) n_done << REC_NDONE_SHIFT) | (steps << REC_STEPS_SHIFT);
+                // (the per-ray step count of the record saturates at 2^20 - 1; the launch total below is exact)
+                m.flags_steps = fl | ((unsigned) n_done << REC_NDONE_SHIFT) |
+                                ((steps < 0xfffffu ? steps : 0xfffffu) << REC_STEPS_SHIFT);
                 // n_done slots were committed: recp stands n_done slots above slot 0 (forward) or below
                 // slot S-1 (backward); the meta block follows slot S-1
                 *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? n_done + 1 : S - n_done)) = m;

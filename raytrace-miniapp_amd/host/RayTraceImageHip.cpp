@@ -9,11 +9,9 @@
 // See INTEGRATION.md for the dispatcher / harness / CMake lines that go with it.
 //
 //   RayTraceImageHipLoop          one device ("hip" arm)
-//   RayTraceImageHipMultiGPULoop  all devices of the node ("hip-multigpu" arm):
-//        contiguous ray chunks like RayTraceImageThreadLoop
-//        (src/RayTraceImage.cpp:89-134), but each worker binds its own device
-//        (the reference calls setGPU in the spawning thread, :116, so its
-//        workers never inherit the device).
+//   RayTraceImageHipMultiGPULoop  all devices of the node ("hip-multigpu" arm) through
+//        rt_hip_multi_image_loop: stands where the reference runs RayTraceImageThreadLoop
+//        (src/RayTraceImage.cpp:89-134) with setGPU called in the spawning thread (:116).
 #include "RayTrace.h"
 #include "common/RayTraceImageHelper.h"
 #include "utilities/RayUtilityMacros.h"
@@ -22,7 +20,6 @@
 
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 static_assert(sizeof(ray_struct) == sizeof(rt_ray), "ray_struct and rt_ray must share a layout");
@@ -107,38 +104,24 @@ void RayTraceImageHipMultiGPULoop(int N, const RayTrace::EUV_beam_struct &beam,
     const std::vector<ray_struct> &rays, double scale, double *image, double *I_ang,
     unsigned int &failure_code, std::vector<ray_struct> &failed_rays)
 {
-    failure_code   = 0;
-    const int ndev = rt_hip_device_count();
-    if (ndev < 1)
+    failure_code = 0;
+    if (rt_hip_device_count() < 1)
         RAY_ERROR("Hip-MultiGPU is not availible");
-    Flat f             = flatten(N, beam, gain, seed);
-    const size_t n_img = (size_t) beam.nx * beam.ny * beam.nv;
-    const size_t n_ang = (size_t) beam.na * beam.nb;
-    const size_t chunk = rays.size() / (size_t) ndev + 1;
-    std::vector<std::vector<double>> img((size_t) ndev), ang((size_t) ndev);
-    std::vector<unsigned int> code((size_t) ndev, 0);
-    std::vector<std::vector<ray_struct>> failed((size_t) ndev);
-    std::vector<std::string> error((size_t) ndev);
-    std::vector<std::thread> workers;
-    for (int d = 0; d < ndev; d++) {
-        const size_t begin = std::min((size_t) d * chunk, rays.size());
-        const size_t count = std::min(chunk, rays.size() - begin);
-        img[(size_t) d].assign(n_img, 0.0);
-        ang[(size_t) d].assign(n_ang, 0.0);
-        workers.push_back(std::thread([&, d, begin, count]() {
-            run_on_device(d, N, f, method, count ? &rays[begin] : NULL, count, scale, img[(size_t) d].data(),
-                          ang[(size_t) d].data(), code[(size_t) d], failed[(size_t) d], error[(size_t) d]);
-        }));
-    }
-    for (int d = 0; d < ndev; d++) {
-        workers[(size_t) d].join();
-        if (!error[(size_t) d].empty())
-            RAY_ERROR(error[(size_t) d]);
-        for (size_t j = 0; j < n_img; j++)
-            image[j] += img[(size_t) d][j];
-        for (size_t j = 0; j < n_ang; j++)
-            I_ang[j] += ang[(size_t) d][j];
-        failure_code |= code[(size_t) d];
-        failed_rays.insert(failed_rays.end(), failed[(size_t) d].begin(), failed[(size_t) d].end());
+    Flat f = flatten(N, beam, gain, seed);
+    rt_ray failed[RT_N_FAILED_MAX];
+    int n_failed      = 0;
+    unsigned int code = 0;
+    // all devices of the node behind one call: pixel-column tiles + one RCCL gather (ASE), ray chunks +
+    // one RCCL sum-reduce otherwise; device binding, communicator and assembly live behind the C ABI
+    int rc = rt_hip_multi_image_loop(0, N, &f.beam, f.gain.data(), f.has_seed ? &f.seed : NULL, method,
+                                     rays.empty() ? NULL : reinterpret_cast<const rt_ray *>(&rays[0]), rays.size(), scale,
+                                     image, I_ang, &code, failed, RT_N_FAILED_MAX, &n_failed, NULL);
+    if (rc != RT_OK)
+        RAY_ERROR(std::string("HIP backend error: ") + rt_hip_last_error());
+    failure_code |= code;
+    for (int i = 0; i < n_failed; i++) {
+        ray_struct r;
+        memcpy(&r, &failed[i], sizeof(r));
+        failed_rays.push_back(r);
     }
 }

@@ -1,85 +1,22 @@
 """Multi-GPU forms of the path.
 
-Two drivers over the same per-device plan:
+One process, all devices: behind the C ABI (rt_hip_multi_image_loop, include/rt_hip.h; Python:
+backend.multi_image_loop / create_image(p, "hip-multigpu")).  This module is the other form:
 
-thread_loop(problem)
-    One process, one host thread per device -- the analogue of the reference's
-    "cuda-multigpu" arm (RayTraceImageThreadLoop, src/RayTraceImage.cpp:89-134,
-    dispatched at :389-405): contiguous ray chunks, private images, summed in
-    device order.  Unlike the reference, the device is bound INSIDE the worker
-    (every C-ABI entry calls hipSetDevice itself), so the parent-thread setGPU
-    defect (RayTraceImage.cpp:116) cannot occur.
-
-shard / assemble (one process per GPU, torch.distributed; backend "nccl" is
-    RCCL over xGMI on ROCm, "gloo" in the CPU tests)
-    ASE    : pixel columns are dealt round-robin to ranks (problem.shard_columns);
-             a rank's image is a compact tile [ny][nx_local][nv]; assembly is an
-             RCCL *gather* of tiles to rank 0 plus an interleave, and a
-             sum-reduce of the na*nb doubles of I_ang.  No other exchange.
-    seeded : source columns are dealt the same way, every rank holds a full
-             private image, assembly is a sum-reduce of image and I_ang (the
-             analogue of intensity_step_struct::sum_reduce,
+shard / Assembler (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm,
+    "gloo" in the CPU tests) -- what bench.py runs at N > 1
+    ASE    : pixel columns are dealt round-robin to ranks (problem.shard_columns); a rank's image is a
+             compact tile [ny][nx_local][nv]; assembly is ONE RCCL gather of (tile | I_ang) buffers to
+             rank 0, one interleave copy and one sum over the I_ang parts.  No other exchange.
+    seeded : source columns are dealt the same way, every rank holds a full private image, assembly
+             is ONE sum-reduce of (image | I_ang) (the analogue of intensity_step_struct::sum_reduce,
              src/RayTraceStructures.cpp:1603-1646).
 """
 from __future__ import annotations
 
-import threading
-
 import numpy as np
 
 from .problem import Problem, shard_columns
-
-
-# --------------------------------------------------------------------------- one process, N devices
-def thread_loop(problem: Problem, n_devices: int | None = None) -> dict:
-    from .backend import HipLibrary, Plan
-
-    hl = HipLibrary.get()
-    ndev = hl.device_count() if n_devices is None else n_devices
-    if ndev < 1:
-        from .backend import RayTraceError
-        raise RayTraceError("Hip-MultiGPU is not availible: no device")
-    first, stride = problem.N_start, problem.N_parallel
-    nt = problem.n_rays_total
-    n_own = 0 if first >= nt else (nt - first + stride - 1) // stride
-    chunk = n_own // ndev + 1  # RayTraceImage.cpp:107: rays.size()/N_threads + 1
-    results: list = [None] * ndev
-    errors: list = [None] * ndev
-
-    def work(d: int) -> None:
-        try:
-            begin = min(d * chunk, n_own)
-            cnt = min(chunk, n_own - begin)
-            with Plan(problem, device=d, lib=hl) as plan:
-                plan.set_ray_grid(first + begin * stride, stride, cnt)
-                results[d] = plan.run().fetch()
-        except Exception as exc:  # noqa: BLE001
-            errors[d] = exc
-
-    threads = [threading.Thread(target=work, args=(d,)) for d in range(ndev)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    for e in errors:
-        if e is not None:
-            raise e
-    b = problem.beam
-    image = np.zeros(b.nx * b.ny * b.nv)
-    iang = np.zeros(b.na * b.nb)
-    code = 0
-    failed = []
-    stats = dict(n_rays=0, cell_steps=0, n_escaped=0, n_skipped=0, kernel_ms=0.0, total_ms=0.0)
-    for r in results:  # join order = device order, as the reference sums
-        image += r["image"]
-        iang += r["I_ang"]
-        code |= r["failure_code"]
-        failed.extend(list(r["failed_rays"]))
-        for k in ("n_rays", "cell_steps", "n_escaped", "n_skipped"):
-            stats[k] += r["stats"][k]
-        stats["kernel_ms"] = max(stats["kernel_ms"], r["stats"]["kernel_ms"])
-        stats["total_ms"] = max(stats["total_ms"], r["stats"]["total_ms"])
-    return dict(image=image, I_ang=iang, failure_code=code, failed_rays=np.array(failed), stats=stats)
 
 
 # --------------------------------------------------------------------------- one process per GPU

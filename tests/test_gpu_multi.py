@@ -1,0 +1,86 @@
+"""The multi-device entry of the C ABI (rt_hip_multi_image_loop: RCCL communicator, pixel-column tiles +
+gather for ASE, ray chunks + sum-reduce otherwise) and the ray-grid recognition of the host-pointer entry.
+The GPU box has ONE device: the communicator is degenerate (self send / self reduce), which still runs
+every line of the multi-device code path; N > 1 is unmeasured on hardware here."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+rt = importlib.import_module("raytrace-miniapp_amd")
+pytestmark = pytest.mark.gpu
+
+
+def test_multi_loop_ase_tiles_equal_the_single_device_image(hip, oracle, ase_small):
+    one = hip.image_loop(ase_small)
+    out = hip.multi_image_loop(ase_small, n_devices=1)
+    assert out["mode"] == 1, "ASE with the beam's own ray grid must take the pixel-tile path"
+    assert out["failure_code"] == 0
+    assert out["stats"]["cell_steps"] == one["stats"]["cell_steps"] == 4768067
+    ref = oracle.image_loop(ase_small, n_threads=8)
+    assert rel_l2(out["image"], ref["image"]) < 1e-6 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-6
+    assert rel_l2(out["image"], one["image"]) < 1e-12 and rel_l2(out["I_ang"], one["I_ang"]) < 1e-12
+
+
+def test_multi_loop_seeded_takes_the_sum_reduce_path(hip, oracle, seed_small):
+    p = rt.scale_problem(seed_small, 0.05)
+    out = hip.multi_image_loop(p, n_devices=1)
+    assert out["mode"] == 2
+    ref = oracle.image_loop(p, n_threads=8)
+    assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    assert rel_l2(out["image"], ref["image"]) < 1e-9 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-9
+
+
+def test_multi_loop_arbitrary_list_falls_back_to_chunks(hip, oracle, ase_small):
+    rays = ase_small.build_rays()[5:-11:3].copy()          # not a tensor grid
+    out = hip.multi_image_loop(ase_small, rays, n_devices=1)
+    assert out["mode"] == 2
+    ref = oracle.image_loop(ase_small, rays, n_threads=8)
+    assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    assert rel_l2(out["image"], ref["image"]) < 1e-6 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-6
+
+
+def test_image_loop_recognises_the_grid_and_survives_a_list_that_only_looks_like_one(hip, oracle, ase_small, monkeypatch):
+    rays = ase_small.build_rays()
+    assert hip.ray_list_grid_dims(rays) == (ase_small.beam.nx, ase_small.beam.ny, ase_small.beam.na, ase_small.beam.nb)
+    a = hip.image_loop(ase_small, rays)                    # rays generated on the device, list verified beside the run
+    monkeypatch.setenv("RT_HIP_NO_GRID_DETECT", "1")
+    b = hip.image_loop(ase_small, rays)                    # list uploaded
+    monkeypatch.delenv("RT_HIP_NO_GRID_DETECT")
+    assert a["stats"]["cell_steps"] == b["stats"]["cell_steps"]
+    assert rel_l2(a["image"], b["image"]) < 1e-12 and rel_l2(a["I_ang"], b["I_ang"]) < 1e-12
+    # one ray moved: the periods still say "grid", the ray-by-ray check says no, the list itself is traced
+    odd = rays.copy()
+    odd["x"][123457] = odd["x"][0]
+    assert hip.ray_list_grid_dims(odd) is None
+    c = hip.image_loop(ase_small, odd)
+    ref = oracle.image_loop(ase_small, odd, n_threads=8)
+    assert c["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    assert rel_l2(c["image"], ref["image"]) < 1e-6 and rel_l2(c["I_ang"], ref["I_ang"]) < 1e-6
+    assert rel_l2(c["image"], a["image"]) > 0
+
+
+def test_pool_trim_and_concurrent_image_loops(hip, ase_small):
+    """Two host threads call the host-pointer entry on one device at once (create_image is documented
+    thread-safe, RayTrace.h:90-91): each call leases its own queue; results are the single-call results."""
+    import threading
+    want = hip.image_loop(ase_small)
+    got = [None, None]
+
+    def run(i):
+        got[i] = hip.image_loop(ase_small)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in got:
+        assert g["stats"]["cell_steps"] == want["stats"]["cell_steps"]
+        assert rel_l2(g["image"], want["image"]) < 1e-12
+    hip.HipLibrary.get().lib.rt_hip_pool_trim()
+    again = hip.image_loop(ase_small)
+    assert rel_l2(again["image"], want["image"]) < 1e-12

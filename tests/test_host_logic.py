@@ -95,3 +95,50 @@ def test_shard_columns_partitions_pixels(ase_small, seed_small):
     assert s.beam.nx == seed_small.beam.nx                       # deposit grid stays whole
     assert np.array_equal(s.seed_beam.x, seed_small.seed_beam.x[1::W])
     assert problem.shard_columns(ase_small, 0, 1) is ase_small
+
+
+# ---- ray list -> tensor grid recognition (include/rt_hip.h, rt_hip_ray_list_grid_dims; host only) ----
+def _grid_rays(nx, ny, na, nb, seed=0):
+    import numpy as np
+    cabi = importlib.import_module("raytrace-miniapp_amd.cabi")
+    rng = np.random.default_rng(seed)
+    g = [np.sort(rng.uniform(-1, 1, n)).astype(np.float32) for n in (nx, ny, na, nb)]
+    ids = np.arange(nx * ny * na * nb)
+    rays = np.empty(len(ids), dtype=cabi.RAY_DTYPE)
+    rays["b"] = g[3][ids % nb]
+    rays["a"] = g[2][(ids // nb) % na]
+    rays["y"] = g[1][(ids // (nb * na)) % ny]
+    rays["x"] = g[0][ids // (nb * na * ny)]
+    return rays
+
+
+@pytest.mark.parametrize("dims", [(5, 4, 3, 2), (7, 1, 1, 3), (1, 1, 1, 9), (3, 5, 1, 1), (1, 6, 2, 1), (64, 32, 7, 5)])
+def test_ray_list_recognised_as_tensor_grid(dims):
+    backend = importlib.import_module("raytrace-miniapp_amd.backend")
+    rays = _grid_rays(*dims)
+    got = backend.ray_list_grid_dims(rays)
+    # axes of length 1 are indistinguishable from their neighbours: what counts is that the product and
+    # the generated order agree, which the library checks ray by ray
+    assert got is not None
+    assert got[0] * got[1] * got[2] * got[3] == len(rays)
+    nz = [d for d in dims if d > 1]
+    assert [d for d in got if d > 1] == nz
+
+
+def test_ray_list_that_is_not_a_grid_is_rejected():
+    import numpy as np
+    backend = importlib.import_module("raytrace-miniapp_amd.backend")
+    rays = _grid_rays(6, 5, 4, 3)
+    assert backend.ray_list_grid_dims(rays) == (6, 5, 4, 3)
+    bad = rays.copy()
+    bad["a"][len(bad) // 2] = np.nextafter(bad["a"][len(bad) // 2], np.float32(9))      # one ulp, one ray
+    assert backend.ray_list_grid_dims(bad) is None
+    assert backend.ray_list_grid_dims(rays[:-1]) is None                                 # ragged tail
+    assert backend.ray_list_grid_dims(rays[::2].copy()) is None or len(rays[::2]) % 2 == 0   # strided subset
+    sw = rays.copy()
+    sw[[3, 4]] = sw[[4, 3]]                                                               # two rays swapped
+    assert backend.ray_list_grid_dims(sw) is None
+    neg = rays.copy()
+    neg["x"][:] = 0.0
+    neg["x"][7] = -0.0                                                                    # -0.0 is not +0.0 bit for bit
+    assert backend.ray_list_grid_dims(neg) is None
