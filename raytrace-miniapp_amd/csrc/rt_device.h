@@ -169,8 +169,16 @@ struct DevParams {
     int32_t *path_err; // [n_rays] return code of each ray
     // step safety factor c of Helper.h:270-313 folded into its three uses (c = 0.5 in create_image)
     float c_cap, c_h1, c_h3, gs_cap; // c*1.00001f, c*0.1f, c*0.05f; see below
-    // gs_cap = 708 / max |gv|: per-sub-segment gain sums are clamped to it before the frequency
-    // pass, so that gs * gv never leaves the range where e^x is a normal double (rt_freq.hip)
+    // gs_cap = 708 / max |gv|: a sub-segment whose gain sum exceeds it in magnitude could take gs * gv
+    // out of the range where e^x is a normal double; it runs the CPU's own formula (overflow to inf,
+    // NaN and all) instead of the fast form of the update (rt_freq.hip)
+    // Rays that fail (error -2 / -3, Helper.h:582-594) are only known after their frequencies have been
+    // integrated -- and, in the normal pass, deposited.  A run that reports such a failure repeats the
+    // frequency pass (rt_hip_plan_fetch): safe = 1 integrates without depositing and marks the failing
+    // rays in bad[], safe = 2 deposits all others.  The CPU loop skips failing rays
+    // (RayTraceImageCPU.cpp:29-36); after the repeat so does this image.  0 = the normal pass.
+    unsigned int safe, pad_safe;
+    unsigned char *bad; // [n_rays], only in the repeat
 };
 
 // packing of RecMeta::flags_steps

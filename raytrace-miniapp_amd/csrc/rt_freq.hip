@@ -280,13 +280,13 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
         P.probe.flags[ridx] = fl | (err1 ? F_ERR1 : 0u);
         P.probe.steps[ridx] = steps;
     }
-    if (err1) { // error -1: the ray is reported and deposits nothing
+    if (err1 && P.safe != 2) { // error -1: the ray is reported and deposits nothing
         atomicOr(&P.ctl->failure_code, 1u << 1);
         unsigned slot_f = atomicAdd(&P.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
             P.ctl->failed[slot_f] = ray;
     }
-    const bool live = have && !err1 && !(fl & F_SKIP);
+    const bool live = have && !err1 && !(fl & F_SKIP) && !(P.safe == 2 && P.bad[ridx]);
     // exclusive mode: this ray is the only contributor of pixel own_pix and must write its
     // whole row (zeros if it contributes nothing); a ray that deposits elsewhere (never the
     // case for a consistent grid) keeps the atomic path for the foreign pixel.
@@ -351,12 +351,11 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             // regular: the source-function form (ase_step) takes this sub-segment; not when the gain
             // sum is tiny or NaN, and never in the exact mode (rt_hip_plan_set_exact_emission), which
             // runs the CPU's own formula with its per-frequency division throughout
-            const bool regular = fabsf(gs[s]) >= RT_RS_MIN && !P.exact_emis;
+            // (|gs| <= gs_cap keeps |gs * gv| <= 708 for every lineshape value; NaN fails both tests)
+            const bool regular = fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= P.gs_cap && !P.exact_emis;
             rs[s]              = regular ? div_fast((double) e1, (double) gs[s]) : 0.0;
             // (a sub-segment with both sums zero is the identity either way: x = 0, e^x - 1 = 0)
             irregular = irregular || (!regular && (gs[s] != 0.0f || e1 != 0.0f));
-            if (use_emis && regular)
-                gs[s] = __builtin_amdgcn_fmed3f(gs[s], -P.gs_cap, P.gs_cap); // keeps |gs * gv| <= 708
         }
     }
     // no such sub-segment in the whole tile (the rule): the six updates of a frequency batch run
@@ -404,7 +403,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     } else
 #pragma unroll
                     for (int s = 0; s < SF; s++) {
-                        if (fabsf(gs[s]) >= RT_RS_MIN && !P.exact_emis) {
+                        if (fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= P.gs_cap && !P.exact_emis) {
                             ase_step(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
                             const float e1 = rec_slot(rec, s, SF, m.flags_steps, P.method == 1).e;
@@ -425,9 +424,9 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
                             wnan[j] = wnan[j] || w.v[j] != w.v[j];
-                        if (fabsf(g1) >= RT_RS_MIN && !P.exact_emis) {
+                        if (fabsf(g1) >= RT_RS_MIN && fabsf(g1) <= P.gs_cap && !P.exact_emis) {
                             const double r1 = div_fast((double) e1, (double) g1);
-                            ase_step(Iv, __builtin_amdgcn_fmed3f(g1, -P.gs_cap, P.gs_cap), r1, w.v, tab);
+                            ase_step(Iv, g1, r1, w.v, tab);
                         } else if (g1 != 0.0f || e1 != 0.0f) {
 #pragma unroll
                             for (int j = 0; j < VEC; j++)
@@ -485,7 +484,8 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                 Iv[j] = Iv[j] * P.scale;                     // RayTraceImageCPU.cpp:59
             }
 #ifndef RT_ABL_NODEPOSIT
-            deposit(kb, Iv);
+            if (P.safe != 1) // the checking pass of a failing run integrates without depositing
+                deposit(kb, Iv);
 #endif
         }
     };
@@ -628,13 +628,16 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     }
     // a NaN intensity makes the I_ang sum NaN (Helper.h:590-593: error -3, after the sign test)
     const bool bad_neg = iv_min < 0.0, bad_nan = angsum != angsum;
-    if (live && (bad_neg || bad_nan)) {
+    if (live && (bad_neg || bad_nan) && P.safe != 2) {
         atomicOr(&P.ctl->failure_code, bad_neg ? (1u << 2) : (1u << 3));
         unsigned slot_f = atomicAdd(&P.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
             P.ctl->failed[slot_f] = ray;
+        if (P.safe == 1)
+            P.bad[ridx] = 1;
     }
-    if (ang >= 0) {
+    // a failing ray adds nothing to I_ang (RayTraceImageCPU.cpp:29-36: `continue` before the deposit)
+    if (ang >= 0 && P.safe != 1 && !(bad_neg || bad_nan)) {
         if (lds_iang)
             unsafeAtomicAdd(&lds_iang[ang], angsum);
         else

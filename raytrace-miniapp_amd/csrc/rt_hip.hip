@@ -245,6 +245,9 @@ struct rt_hip_plan {
     hipStream_t last_stream = nullptr;
     double *last_image = nullptr, *last_iang = nullptr;
     bool ran = false;
+    bool repeated = false; // the checking repeat of the frequency pass has run for the last run
+    unsigned char *bad_dev = nullptr; // failing-ray marks of the checking repeat (plan_repeat_checked)
+    size_t bad_rays        = 0;
     std::chrono::steady_clock::time_point t_created;
 };
 
@@ -333,6 +336,50 @@ static void plan_quiesce(rt_hip_plan *p)
         if (hipStreamSynchronize(p->last_stream) != hipSuccess)
             (void) hipGetLastError(); // a caller's stream that is gone: nothing is in flight on it
     }
+}
+
+static int launch_freq_any(rt_hip_plan *p, hipStream_t stream)
+{
+    const int S = p->P.L * RT_N_SUB;
+    if (p->P.use_emis)
+        return (S == 6) ? launch_freq<6, true>(p, stream, 0) : launch_freq<0, true>(p, stream, 0);
+    return (S == 6) ? launch_freq<6, false>(p, stream, 0) : launch_freq<0, false>(p, stream, 0);
+}
+
+// A run whose frequency pass reported failing rays (error -2 / -3) has deposited them: repeat the pass
+// over the same march records, first integrating without depositing to mark the failing rays, then
+// depositing all others (DevParams::safe).  Leaves image / I_ang as the CPU loop leaves them
+// (RayTraceImageCPU.cpp:29-36) and the failure report as the first pass of the repeat gives it.
+static int plan_repeat_checked(rt_hip_plan *p)
+{
+    hipStream_t stream = p->last_stream;
+    if (p->bad_rays < (size_t) p->n_rays || !p->bad_dev) {
+        (void) hipFree(p->bad_dev);
+        p->bad_dev = nullptr;
+        HIP_TRY(dev_malloc((void **) &p->bad_dev, (size_t) p->n_rays + 16));
+        p->bad_rays = (size_t) p->n_rays;
+    }
+    HIP_TRY(hipMemsetAsync(p->bad_dev, 0, (size_t) p->n_rays, stream));
+    HIP_TRY(hipMemsetAsync(&p->ctl->failure_code, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(&p->ctl->n_failed, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(&p->ctl->next_tile_b, 0, sizeof(unsigned), stream));
+    p->P.bad  = p->bad_dev;
+    p->P.safe = 1;
+    int rc    = launch_freq_any(p, stream);
+    if (rc == RT_OK) {
+        if (!p->P.exclusive)
+            HIP_TRY(hipMemsetAsync(p->last_image, 0, p->n_image * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(p->last_iang, 0, p->n_iang * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(&p->ctl->next_tile_b, 0, sizeof(unsigned), stream));
+        p->P.safe = 2;
+        rc        = launch_freq_any(p, stream);
+    }
+    p->P.safe = 0;
+    p->P.bad  = nullptr;
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RT_OK;
 }
 
 // Two-kernel path: march (persistent lanes) -> records in HBM -> frequency pass.
@@ -441,12 +488,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
             HIP_TRY(hipGetLastError());
         }
     } else if (!(p->P.debug & 1u)) {
-        const int S = p->P.L * RT_N_SUB;
-        int rc;
-        if (p->P.use_emis)
-            rc = (S == 6) ? launch_freq<6, true>(p, stream, 0) : launch_freq<0, true>(p, stream, 0);
-        else
-            rc = (S == 6) ? launch_freq<6, false>(p, stream, 0) : launch_freq<0, false>(p, stream, 0);
+        const int rc = launch_freq_any(p, stream);
         if (rc != RT_OK)
             return rc;
     }
@@ -511,6 +553,7 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
     (void) hipFree(p->iang_own);
     (void) hipFree(p->ctl);
     (void) hipFree(p->probe);
+    (void) hipFree(p->bad_dev);
     delete p;
 }
 
@@ -1064,6 +1107,7 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     p->last_image  = image_dev;
     p->last_iang   = iang_dev;
     p->ran         = true;
+    p->repeated    = false;
     return RT_OK;
 }
 
@@ -1074,6 +1118,17 @@ int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int
         return fail_arg("rt_hip_plan_fetch: plan has not run");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->last_stream));
+    {
+        // rays that failed in the frequency pass have been deposited: repeat the pass without them
+        unsigned code = 0;
+        HIP_TRY(hipMemcpy(&code, &p->ctl->failure_code, sizeof(code), hipMemcpyDeviceToHost));
+        if ((code & ((1u << 2) | (1u << 3))) && !p->path_on && !(p->P.debug & 1u) && !p->repeated) {
+            const int rc = plan_repeat_checked(p);
+            if (rc != RT_OK)
+                return rc;
+            p->repeated = true; // this run's outputs are final; a second fetch must not repeat again
+        }
+    }
     if (image)
         HIP_TRY(hipMemcpy(image, p->last_image, p->n_image * sizeof(double), hipMemcpyDeviceToHost));
     if (I_ang)
@@ -1596,6 +1651,13 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
             if (rc != RT_OK)
                 fail(rc, rt_hip_last_error());
         }
+        // counters and failure report of this device; a run with failing rays repeats its frequency pass
+        // here (rt_hip_plan_fetch), before its result travels
+        if (w.rc == RT_OK) {
+            const int rc = rt_hip_plan_fetch(p, nullptr, nullptr, &w.code, w.failed, RT_N_FAILED_MAX, &w.n_failed, &w.st);
+            if (rc != RT_OK)
+                fail(rc, rt_hip_last_error());
+        }
         // -- the one collective of the image, on the queue the kernels ran on
         if (meet.arrive(w.rc == RT_OK)) {
             ncclResult_t r = ncclSuccess;
@@ -1626,11 +1688,6 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                 hip_ok(hipMemcpy(image, out0, n_img * sizeof(double), hipMemcpyDeviceToHost), "download image");
                 hip_ok(hipMemcpy(I_ang, out0 + n_img, n_ang * sizeof(double), hipMemcpyDeviceToHost), "download I_ang");
             }
-        }
-        if (w.rc == RT_OK) {
-            const int rc = rt_hip_plan_fetch(p, nullptr, nullptr, &w.code, w.failed, RT_N_FAILED_MAX, &w.n_failed, &w.st);
-            if (rc != RT_OK)
-                fail(rc, rt_hip_last_error());
         }
         // every worker is past the collective before any buffer of it goes back to the pool
         meet.arrive(true);

@@ -78,15 +78,106 @@ __device__ __attribute__((noinline)) float atan_wide(float x) { return (float) a
 // the fdlibm float kernel: for |x| < 0.6744 a degree-13 odd polynomial evaluated in float
 // in a fixed order.  Restated here (same coefficients, same order, no FMA contraction);
 // tests/test_float_identities.py checks the restatement against the host tanf for every
-// float in [4.6e-10, 0.2].  Launch angles beyond 200 mrad fall back to the float-rounded
-// f64 tan (the float kernel's large-argument branches are not restated).
+// float in [4.6e-10, 0.2].  Launch angles beyond 200 mrad: tanf_flt32_wide below.
+// The other branches of the same libm routine, for launch angles of 200 mrad ... 1.375 rad: k_tanf.c
+// with its |x| >= 0.6744 transformation and its accurate -1/(x + r), behind the first case (|x| < 3 pi/4,
+// n = +-1) of the float argument reduction e_rem_pio2f.c.  Checked against the host tanf for EVERY float of
+// [0.2, 1.375] (tests/test_float_identities.py): 0 mismatches; closer to pi/2 the host differs in the last
+// bit for 5e-5 of the floats, so beyond 1.375 rad (where a ray is 79 degrees off the axis and fails the
+// s.z^2 >= 0.01 test of Helper.h:515 anyway) the float-rounded f64 tangent stands in.  Out of line: only
+// rt_tan_kernel calls it.
+__device__ __attribute__((noinline)) float ktanf_flt32(float x, float y, int iy)
+{
+    const float T[13] = { 3.3333334327e-01f, 1.3333334029e-01f, 5.3968254477e-02f, 2.1869488060e-02f, 8.8632395491e-03f,
+                          3.5920790397e-03f, 1.4562094584e-03f, 5.8804126456e-04f, 2.4646313977e-04f, 7.8179444245e-05f,
+                          7.1407252108e-05f, -1.8558637748e-05f, 2.5907305826e-05f };
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    float z, r, v, w, s;
+    const int hx = (int) __float_as_uint(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {
+        if ((int) x == 0) {
+            if ((ix | (iy + 1)) == 0)
+                return 1.0f / fabsf(x);
+            else if (iy == 1)
+                return x;
+            else
+                return -1.0f / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) { // |x| >= 0.6744
+        if (hx < 0) {
+            x = -x;
+            y = -y;
+        }
+        z = pio4 - x;
+        w = pio4lo - y;
+        x = z + w;
+        y = 0.0f;
+        if (fabsf(x) < 0x1p-13f)
+            return (1 - ((hx >> 30) & 2)) * iy * (1.0f - 2 * iy * x);
+    }
+    z = x * x;
+    w = z * z;
+    r = T[1] + w * (T[3] + w * (T[5] + w * (T[7] + w * (T[9] + w * T[11]))));
+    v = z * (T[2] + w * (T[4] + w * (T[6] + w * (T[8] + w * (T[10] + w * T[12])))));
+    s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T[0] * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float) iy;
+        return (float) (1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1)
+        return w;
+    // -1 / (x + r), accurately
+    float a, t;
+    z = __uint_as_float(__float_as_uint(w) & 0xfffff000u);
+    v = r - (z - x);
+    t = a = -1.0f / w;
+    t = __uint_as_float(__float_as_uint(t) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+__device__ __attribute__((noinline)) float tanf_flt32_wide(float x)
+{
+    const float pio2_1 = 1.5707855225e+00f, pio2_1t = 1.0804334124e-05f, pio2_2 = 1.0804273188e-05f,
+                pio2_2t = 6.0770999344e-11f;
+    const int hx = (int) __float_as_uint(x), ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) // |x| <= pi/4
+        return ktanf_flt32(x, 0.0f, 1);
+    float y0, y1, z;
+    if (hx > 0) {
+        z = x - pio2_1;
+        if ((ix & 0xfffffff0) != 0x3fc90fd0) {
+            y0 = z - pio2_1t;
+            y1 = (z - y0) - pio2_1t;
+        } else {
+            z -= pio2_2;
+            y0 = z - pio2_2t;
+            y1 = (z - y0) - pio2_2t;
+        }
+    } else {
+        z = x + pio2_1;
+        if ((ix & 0xfffffff0) != 0x3fc90fd0) {
+            y0 = z + pio2_1t;
+            y1 = (z - y0) + pio2_1t;
+        } else {
+            z += pio2_2;
+            y0 = z + pio2_2t;
+            y1 = (z - y0) + pio2_2t;
+        }
+    }
+    return ktanf_flt32(y0, y1, -1);
+}
+
 __device__ __forceinline__ float tanf_flt32_kernel(float x)
 {
     const float ax = fabsf(x);
     if (ax < 0x1p-13f) // s_tanf.c/k_tanf.c: (int) x == 0 -> return x
         return x;
     if (ax > 0.2f)
-        return tan_wide(x);
+        return ax <= 1.375f ? tanf_flt32_wide(x) : tan_wide(x);
     const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
                 T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
                 T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,

@@ -139,6 +139,21 @@ def test_two_sided_y_grid_takes_the_unmirrored_branch(hip, oracle, ase_small):
     assert rel_l2(out["image"], ref["image"]) < TIGHT
 
 
+def same_outputs_in_a_failing_run(out, ref, tol=1e-6):
+    """Failing rays deposit nothing on the CPU (RayTraceImageCPU.cpp:29-36: `continue` before the deposit);
+    the backend repeats its frequency pass without them (include/rt_hip.h), so image and I_ang of a failing
+    run are the CPU's: same non-finite entries (an overflow to +inf is not an error on the CPU either), same
+    finite values."""
+    for key in ("image", "I_ang"):
+        a, b = out[key], ref[key]
+        fa, fb = np.isfinite(a), np.isfinite(b)
+        assert np.array_equal(fa, fb), key
+        assert np.array_equal(np.isnan(a), np.isnan(b)), key
+        assert np.array_equal(a[~fa & ~np.isnan(a)], b[~fb & ~np.isnan(b)]), key   # signed infinities
+        nb = np.linalg.norm(b[fb])
+        assert np.linalg.norm(a[fa] - b[fb]) <= tol * nb if nb > 0 else np.all(a[fa] == 0), key
+
+
 def test_failure_codes_match_the_cpu_loop(hip, oracle, ase_small):
     ids = np.arange(0, ase_small.n_rays_total, 997, dtype=np.int64)
     rays = ase_small.build_rays(ids)
@@ -156,11 +171,13 @@ def test_failure_codes_match_the_cpu_loop(hip, oracle, ase_small):
     p.gain = ase_small.gain[:2] + [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv)]
     out, ref = run_hip(hip, p, rays), oracle.image_loop(p, rays)
     assert ref["failure_code"] & (1 << 3) and out["failure_code"] == ref["failure_code"]
+    same_outputs_in_a_failing_run(out, ref)
     # error -2: negative lineshape -> negative intensity
     gv = -np.abs(g.gv)
     p.gain = ase_small.gain[:2] + [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv)]
     out, ref = run_hip(hip, p, rays), oracle.image_loop(p, rays)
     assert ref["failure_code"] & (1 << 2) and out["failure_code"] == ref["failure_code"]
+    same_outputs_in_a_failing_run(out, ref)
     with pytest.raises(hip.RayTraceError, match="Some rays failed"):
         hip.create_image(p, "hip")
 
@@ -304,3 +321,53 @@ def test_sliced_ray_upload_of_the_host_pointer_entry(hip, oracle, ase_small, mon
     ref = oracle.image_loop(ase_small, rays)
     assert whole["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
     assert rel_l2(whole["image"], ref["image"]) < TIGHT
+
+
+def test_gain_beyond_the_range_of_exp_matches_the_cpu_loop(hip, oracle, ase_small, seed_small):
+    """|gvl * gv| > 708 (Helper.h:549-557, :575-579): e^gl overflows on the CPU -- +inf, or 0 * inf = NaN and
+    error -3.  The fast form of the update is only taken below that range; beyond it the CPU's own formula
+    runs, so failure code, failed-ray handling and the image equal the CPU loop's, in both modes."""
+    def boosted(p, f):
+        q = copy.copy(p)
+        q.gain = [rt.Gain(g.x, g.y, g.n, g.g0 * np.float32(f), g.E0, g.gv, g.Nv) for g in p.gain]
+        return q
+
+    ids = np.arange(0, ase_small.n_rays_total, 499, dtype=np.int64)
+    rays = ase_small.build_rays(ids)
+    hit = 0
+    for f in (40.0, 700.0, 1e30):
+        p = boosted(ase_small, f)
+        out, ref = run_hip(hip, p, rays), oracle.image_loop(p, rays)
+        assert out["failure_code"] == ref["failure_code"], f
+        assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+        same_outputs_in_a_failing_run(out, ref)
+        hit += ref["failure_code"] != 0 or not np.isfinite(ref["image"]).all()
+    assert hit >= 2, "the test must reach the overflow regime"
+    ids = np.arange(1, seed_small.n_rays_total, 4999, dtype=np.int64)
+    rays = seed_small.build_rays(ids)
+    hit = 0
+    for f in (40.0, 700.0):
+        p = boosted(seed_small, f)
+        out, ref = run_hip(hip, p, rays), oracle.image_loop(p, rays)
+        assert out["failure_code"] == ref["failure_code"], f
+        same_outputs_in_a_failing_run(out, ref)
+        hit += ref["failure_code"] != 0 or not np.isfinite(ref["image"]).all()
+    assert hit >= 1
+
+
+def test_wide_launch_angles_in_list_mode(hip, oracle, ase_small):
+    """List-mode launch angles of 200 ... 800 mrad (Helper.h:409-411: tanf(1e-3f * a)): beyond the range of
+    the restated float kernel the device used the float-rounded f64 tangent, which is not always tanf.  The
+    march record must equal the CPU loop's whatever the angle."""
+    ids = np.arange(0, ase_small.n_rays_total, 211, dtype=np.int64)
+    rays = ase_small.build_rays(ids)
+    rng = np.random.default_rng(5)
+    rays["a"] = rng.uniform(-800.0, 800.0, len(rays)).astype(np.float32)
+    rays["b"] = rng.uniform(-800.0, 800.0, len(rays)).astype(np.float32)
+    rays["a"][::3] = np.sign(rays["a"][::3]) * rng.uniform(200.0, 800.0, len(rays[::3])).astype(np.float32)
+    out = run_hip(hip, ase_small, rays, probe=True)
+    ora = oracle.probe(ase_small, rays, want_Iv=False)
+    same_record(out["probe"], ora)
+    ref = oracle.image_loop(ase_small, rays)
+    assert out["failure_code"] == ref["failure_code"]
+    same_outputs_in_a_failing_run(out, ref, tol=1e-5)
