@@ -60,6 +60,10 @@ Flat flatten(int N, const RayTrace::EUV_beam_struct &b, const RayTrace::ray_gain
     return f;
 }
 
+// counters and device times of the last loop call of this thread (the loop signature has no slot for
+// them): read by harnesses that print ray-steps/s next to the reference's timing table
+thread_local rt_stats g_last_stats = {};
+
 void run_on_device(int device, int N, const Flat &f, int method, const ray_struct *rays, size_t n_rays,
                    double scale, double *image, double *I_ang, unsigned int &failure_code,
                    std::vector<ray_struct> &failed_rays, std::string &error)
@@ -69,7 +73,7 @@ void run_on_device(int device, int N, const Flat &f, int method, const ray_struc
     unsigned int code = 0;
     int rc = rt_hip_image_loop(device, N, &f.beam, f.gain.data(), f.has_seed ? &f.seed : NULL, method,
                                reinterpret_cast<const rt_ray *>(rays), n_rays, scale, image, I_ang, &code,
-                               failed, RT_N_FAILED_MAX, &n_failed, NULL);
+                               failed, RT_N_FAILED_MAX, &n_failed, &g_last_stats);
     if (rc != RT_OK) {
         error = std::string("HIP backend error: ") + rt_hip_last_error();
         return;
@@ -85,6 +89,9 @@ void run_on_device(int device, int N, const Flat &f, int method, const ray_struc
 } // namespace
 
 int RayTraceImageHipDeviceCount() { return rt_hip_device_count(); }
+
+// rt_stats of the last RayTraceImageHip*Loop call made by the calling thread
+const rt_stats *RayTraceImageHipLastStats() { return &g_last_stats; }
 
 void RayTraceImageHipLoop(int N, const RayTrace::EUV_beam_struct &beam, const RayTrace::ray_gain_struct *gain,
     const RayTrace::ray_seed_struct *seed, int method, const std::vector<ray_struct> &rays, double scale,
@@ -115,7 +122,7 @@ void RayTraceImageHipMultiGPULoop(int N, const RayTrace::EUV_beam_struct &beam,
     // one RCCL sum-reduce otherwise; device binding, communicator and assembly live behind the C ABI
     int rc = rt_hip_multi_image_loop(0, N, &f.beam, f.gain.data(), f.has_seed ? &f.seed : NULL, method,
                                      rays.empty() ? NULL : reinterpret_cast<const rt_ray *>(&rays[0]), rays.size(), scale,
-                                     image, I_ang, &code, failed, RT_N_FAILED_MAX, &n_failed, NULL);
+                                     image, I_ang, &code, failed, RT_N_FAILED_MAX, &n_failed, &g_last_stats);
     if (rc != RT_OK)
         RAY_ERROR(std::string("HIP backend error: ") + rt_hip_last_error());
     failure_code |= code;
