@@ -177,7 +177,8 @@ struct DevParams {
     // frequency pass (rt_hip_plan_fetch): safe = 1 integrates without depositing and marks the failing
     // rays in bad[], safe = 2 deposits all others.  The CPU loop skips failing rays
     // (RayTraceImageCPU.cpp:29-36); after the repeat so does this image.  0 = the normal pass.
-    unsigned int safe, pad_safe;
+    unsigned int safe;
+    unsigned int park; // march: lanes that must wait for block [A] before it runs (rt_march.hip); 1 = every iteration
     unsigned char *bad; // [n_rays], only in the repeat
 };
 

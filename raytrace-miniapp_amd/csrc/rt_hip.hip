@@ -429,6 +429,9 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     ch                    = ch < 16 ? 16 : (ch > 512 ? 512 : ch);
     p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
     p->P.chunk = env_unsigned("RT_HIP_MARCH_CHUNK", p->P.chunk, 1, 1u << 20); // tuning
+    // lanes that must wait for block [A] of the march before it runs (swept 1 ... 40 on the 6.4 M-ray
+    // stand-in: 2.36 ms at 1, flat optimum 2.12 ms at 8 ... 24, 2.63 ms at 40)
+    p->P.park    = env_unsigned("RT_HIP_MARCH_PARK", 12, 1, 64);
     p->P.path_on = p->path_on ? 1u : 0u;
     if (p->path_on) {
         const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
@@ -647,7 +650,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     // march blob: headers + grids + fused corner nodes of every length, copied to LDS
     // verbatim by rt_march_kernel<true>
     std::vector<unsigned char> blob(align_up(sizeof(rt::BlobGain) * (size_t) N, 16));
-    bool tiny_spacing = false;
+    bool tiny_spacing = false, bad_index = false;
     for (int i = 1; i < N; i++) {
         const rt_gain &g  = gain[i];
         const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
@@ -678,8 +681,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             memset(iv, 0, sizeof(rt::Interval) * (size_t) n);
             for (int k = 1; k < n; k++) {
                 const double lo = gp[k - 1], hi = gp[k], hk = hi - lo;
-                if (hk > 0.0 && hk < 1e-200)
-                    tiny_spacing = true; // see rt_math.h, div_by_recip<TINY_OK>
+                if (!(hk >= 1e-30)) // see rt_math.h, div_by_recip<TINY_OK>; and the integrator's step limits
+                    tiny_spacing = true; // 0.1f * (float) hk must be positive (rt_march.hip, block [C])
                 iv[k].lo   = lo;
                 iv[k].hi   = hi;
                 iv[k].rh   = 1.0 / hk;
@@ -698,6 +701,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         blob.resize(blob.size() + sizeof(rt::Node) * npix);
         rt::Node *nd = reinterpret_cast<rt::Node *>(blob.data() + h.off_node);
         for (size_t c = 0; c < npix; c++) { // the three gathered quantities fused per grid point
+            if (!std::isfinite(g.n[c]))
+                bad_index = true; // (the reference's integrator loop would never advance: Helper.h:279-280)
             nd[c].n  = g.n[c];
             nd[c].g0 = g.g0[c];
             nd[c].E0 = g.E0 ? g.E0[c] : 0.0f;
@@ -706,7 +711,11 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     }
     if (tiny_spacing) {
         delete p;
-        return fail_arg("rt_hip_plan_create: gain grid spacing below 1e-200");
+        return fail_arg("rt_hip_plan_create: gain grid not strictly increasing, or spacing below 1e-30");
+    }
+    if (bad_index) {
+        delete p;
+        return fail_arg("rt_hip_plan_create: non-finite index of refraction");
     }
     const size_t off_blob = ab.put(blob.data(), blob.size());
 

@@ -337,11 +337,12 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     float z = 0.0f, z_stop = 0.0f;
     float px = 0, py = 0, pz = 0, sx = 0, sy = 0, sz = 1;
     float gacc = 0, eacc = 0;
-    int cell_last = 0, n_done = 0;
+    int cell_last = 0, sub = 0; // sub: sub-segments committed so far (slots written), 0 .. S
     unsigned char *recp = P.rec; // slot of the lane's current sub-segment inside its ray's record
     BlobGain G    = hdr[1]; // header of the lane's current length ii, re-read only when ii changes
     unsigned steps = 0;
-    bool escaped = false, any_nz = false, mirror = false;
+    bool escaped = false, mirror = false;
+    unsigned any_bits = 0; // OR of the magnitude bits of every committed gain / emission sum: 0 <=> all were zero
     // cell
     int c00 = 0;                              // index of the lower-left corner node of the current cell
     // refractive index at the cell's four corners (gathered in [A2] with g0, E0), as block [B] uses it:
@@ -436,7 +437,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 cell_last = 0;
                 steps     = 0;
                 escaped   = false;
-                any_nz    = false;
+                any_bits  = 0;
+                sub       = 0;
                 st        = ST_CELL;
             }
         }
@@ -450,16 +452,21 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // Straight-line: at most one sub-segment end [A1] and one cell setup [A2] per wave
         // iteration (a lane that needs more -- several empty sub-segments in a row, or the
         // commit after an escape -- simply comes back next iteration).
-        if (st == ST_CELL) {
+        // Lane parking: block [A] costs as much as [C] but only a third of the lanes need it in any one
+        // iteration; with P.park > 1 it runs only when at least that many lanes wait for it (or nobody
+        // has anything else to do), the waiting lanes sit the iteration out.
+        const unsigned long long want_a = __ballot(st == ST_CELL);
+        const bool do_a = (int) __popcll(want_a) >= (int) P.park || __ballot((st == ST_XSETUP) | (st == ST_STEP)) == 0ull;
+        if (do_a && st == ST_CELL) {
             bool in_seg        = !escaped & (z < 0.995f * z_stop);
             if (!in_seg) {
                 // [A1] end of this sub-segment: commit its slot (Helper.h:501-503 accumulate from 0),
-                // slot (ii - 1) * 3 + (backward ? 2 - iz : iz)
+                // slot (ii - 1) * 3 + (backward ? 2 - iz : iz); straight-line, selects instead of branches
 #ifndef RT_ABL_NOSTORE
                 *reinterpret_cast<RecSlot *>(recp) = RecSlot{ gacc, eacc, cell_last };
 #endif
                 recp += backward ? -12 : 12;
-                any_nz    = any_nz | (gacc != 0.0f) | (eacc != 0.0f);
+                any_bits |= (__float_as_uint(gacc) | __float_as_uint(eacc)) & 0x7fffffffu;
                 if (P.path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
                                  // segment records the same position, later segments stay zero
                     float *pp = P.path + (size_t) ridx * 3 * (size_t) (S + 1);
@@ -472,27 +479,21 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 gacc      = 0.0f;
                 eacc      = 0.0f;
                 cell_last = 0;
-                if (escaped) {
-                    // the remaining sub-segments are never entered: RecMeta::n_done tells the readers
-                    n_done = seg * RT_N_SUB + iz + 1;
-                    st = ST_DONE;
-                } else {
-                    if (++iz == RT_N_SUB) {
-                        iz = 0;
-                        ++seg;
-                        ii = backward ? P.N - seg - 1 : seg + 1;
-                        z  = 0.0f;
-                        if (seg < L)
-                            G = hdr[ii];
-                    }
-                    if (seg == L) {
-                        n_done = S;
-                        st     = ST_DONE;
-                    } else {
-                        z_stop = iz == 0 ? zs0 : (iz == 1 ? zs1 : zs2);
-                        in_seg = z < 0.995f * z_stop;
-                    }
+                sub++;
+                // an escaped ray never enters its remaining sub-segments: `sub` tells the readers
+                // (RecMeta n_done); otherwise on to the next sub-segment, or the next segment
+                const bool wrap = iz == RT_N_SUB - 1;
+                const bool fin  = escaped | (sub == S);
+                iz              = wrap ? 0 : iz + 1;
+                z               = wrap ? 0.0f : z;
+                st              = fin ? ST_DONE : ST_CELL;
+                if (wrap & !fin) { // twice per ray
+                    seg++;
+                    ii = backward ? P.N - seg - 1 : seg + 1;
+                    G  = hdr[ii];
                 }
+                z_stop = iz == 0 ? zs0 : (iz == 1 ? zs1 : zs2);
+                in_seg = !fin & (z < 0.995f * z_stop);
             }
             RT_MARK(1); // [A1]
             if ((st == ST_CELL) & in_seg) {
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 unsigned fl = F_VALID;
                 if (escaped)
                     fl |= F_ESCAPED;
-                if (use_emis && !any_nz)
+                if (use_emis && any_bits == 0u)
                     fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0
                 RecMeta m;
                 m.px          = px;
@@ -586,11 +587,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 m.sy          = sy;
                 m.sz          = sz;
                 // (the per-ray step count of the record saturates at 2^20 - 1; the launch total below is exact)
-                m.flags_steps = fl | ((unsigned) n_done << REC_NDONE_SHIFT) |
+                m.flags_steps = fl | ((unsigned) sub << REC_NDONE_SHIFT) |
                                 ((steps < 0xfffffu ? steps : 0xfffffu) << REC_STEPS_SHIFT);
-                // n_done slots were committed: recp stands n_done slots above slot 0 (forward) or below
+                // `sub` slots were committed: recp stands that many slots above slot 0 (forward) or below
                 // slot S-1 (backward); the meta block follows slot S-1
-                *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? n_done + 1 : S - n_done)) = m;
+                *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? sub + 1 : S - sub)) = m;
                 tot_steps += steps;
                 tot_esc += escaped ? 1u : 0u;
                 tot_skip += (fl & F_SKIP) ? 1u : 0u;
@@ -628,9 +629,13 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // ------------------------------------------------------------ [C] one integrator step (Helper.h:279-311)
         if (st == ST_STEP) {
             const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
-            // (double)|n - n0| < 0.05 (Helper.h:280) <=> |n - n0| < 0.05f: 0.05f is the smallest float above 0.05
-            bool run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & (fabsf(n - n0) < 0.05f);
-            if (run) {
+            // The loop condition of Helper.h:279-280 holds for every lane that arrives here: a lane from [B]
+            // has r = 0, n = n0 and limits that are positive (cell widths are, rt_hip_plan_create checks it;
+            // lim2 = dzrem - zc > 0 is the entry condition of [B]); a lane that stays in this state was
+            // tested at the end of its last step, below.  So the step runs unconditionally and the
+            // condition is evaluated once, after it.
+            bool run;
+            {
                 n        = n0 + rx * gxn + ry * gyn;
 #ifdef RT_ABL_FASTDIV
 #define RT_FDIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
@@ -688,6 +693,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 renormalise(sx, sy, sz);
                 hsum += h;
                 RT_TICK(0);
+                // (double)|n - n0| < 0.05 (Helper.h:280) <=> |n - n0| < 0.05f: 0.05f is the smallest float above 0.05
                 run = (fabsf(rx) < lim0) & (fabsf(ry) < lim1) & (fabsf(rz) < lim2) & (fabsf(n - n0) < 0.05f);
             }
             if (!run) {
