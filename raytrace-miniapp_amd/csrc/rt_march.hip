@@ -505,28 +505,35 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     mirror              = G.mirror_y != 0;
                     const Interval *ivx = reinterpret_cast<const Interval *>(tab + G.off_ix);
                     const Interval *ivy = reinterpret_cast<const Interval *>(tab + G.off_iy);
-                    const Node *node    = reinterpret_cast<const Node *>(tab + G.off_node);
+                    // (records are addressed by 32-bit byte offsets from the start of the blob: no
+                    // 64-bit multiplies for what is an LDS address)
+                    auto interval_at = [&](int off, int u) {
+                        return *reinterpret_cast<const Interval *>(tab + ((unsigned) off + (unsigned) u * (unsigned) sizeof(Interval)));
+                    };
+                    auto node_at = [&](int c) {
+                        return *reinterpret_cast<const Node *>(tab + ((unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node)));
+                    };
                     const float ya      = mirror ? fabsf(py) : py;
                     const double pxd = (double) px, yad = (double) ya;
                     // one round of gathers on the guessed cell: two interval records, four nodes
                     int k1     = guess_interval(G.Nx, G.x0f, G.inv_hxf, px);
                     int k2     = guess_interval(G.Ny, G.y0f, G.inv_hyf, ya);
-                    Interval X = ivx[k1], Y = ivy[k2];
+                    Interval X = interval_at(G.off_ix, k1), Y = interval_at(G.off_iy, k2);
                     c00        = (k1 - 1) + (k2 - 1) * G.Nx;
-                    Node a00 = node[c00], a10 = node[c00 + 1];
-                    Node a01 = node[c00 + G.Nx], a11 = node[c00 + G.Nx + 1];
+                    Node a00 = node_at(c00), a10 = node_at(c00 + 1);
+                    Node a01 = node_at(c00 + G.Nx), a11 = node_at(c00 + G.Nx + 1);
                     const bool ok = ((k1 == 1) | (X.lo < pxd)) & ((k1 == G.Nx - 1) | (X.hi >= pxd)) &
                                     ((k2 == 1) | (Y.lo < yad)) & ((k2 == G.Ny - 1) | (Y.hi >= yad));
                     if (!ok) {
                         k1  = bisect_interval(ivx, G.Nx, pxd);
                         k2  = bisect_interval(ivy, G.Ny, yad);
-                        X   = ivx[k1];
-                        Y   = ivy[k2];
+                        X   = interval_at(G.off_ix, k1);
+                        Y   = interval_at(G.off_iy, k2);
                         c00 = (k1 - 1) + (k2 - 1) * G.Nx;
-                        a00 = node[c00];
-                        a10 = node[c00 + 1];
-                        a01 = node[c00 + G.Nx];
-                        a11 = node[c00 + G.Nx + 1];
+                        a00 = node_at(c00);
+                        a10 = node_at(c00 + 1);
+                        a01 = node_at(c00 + G.Nx);
+                        a11 = node_at(c00 + G.Nx + 1);
                     }
                     f00       = (float) a00.n;
                     f10       = (float) a10.n;
@@ -591,7 +598,12 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                                 ((steps < 0xfffffu ? steps : 0xfffffu) << REC_STEPS_SHIFT);
                 // `sub` slots were committed: recp stands that many slots above slot 0 (forward) or below
                 // slot S-1 (backward); the meta block follows slot S-1
+#ifndef RT_ABL_NOMETA
                 *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? sub + 1 : S - sub)) = m;
+#else
+                if (m.px == 1234.5f) // profiling only: the store stays reachable, but never happens
+                    *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? sub + 1 : S - sub)) = m;
+#endif
                 tot_steps += steps;
                 tot_esc += escaped ? 1u : 0u;
                 tot_skip += (fl & F_SKIP) ? 1u : 0u;
@@ -644,9 +656,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 #endif
                 const float rn = RT_FDIV(1.0f, n); // one IEEE division, three exact quotients
                 float a0 = sx * gxn + sy * gyn + 1e-12f;
-                float t  = div_by_recip<true>(a0, n, rn);
-                float qx = div_by_recip<true>(gxn, n, rn);
-                float qy = div_by_recip<true>(gyn, n, rn);
+                float t  = div_by_recip_signed(a0, n, rn);
+                float qx = div_by_recip_signed(gxn, n, rn);
+                float qy = div_by_recip_signed(gyn, n, rn);
 #ifndef RT_ABL_NOGUARD
                 // div_by_recip needs a true division for non-zero dividends below 1e-29 (rt_math.h).  One
                 // wave-uniform test covers the three quotients: the smallest magnitude of the dividends is

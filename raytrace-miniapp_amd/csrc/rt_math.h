@@ -86,7 +86,9 @@ __device__ __forceinline__ float inv_norm(float q)
 #ifdef RT_ABL_FASTDIV
     inv = __builtin_amdgcn_rsqf(q);
 #else
-    if (fabsf(q - 1.0f) < 0.0625f) {
+    {
+        // the shortcut for every lane; the IEEE sequence replaces it behind ONE wave-uniform branch in
+        // the (never observed) case that some lane's q lies outside the shortcut's range
         const float y    = __builtin_amdgcn_rsqf(q);
         const float s0   = q * y;
         const float e    = fmaf(-s0, s0, q);
@@ -95,9 +97,11 @@ __device__ __forceinline__ float inv_norm(float q)
         inv              = fmaf(r, y, y);
         const unsigned u = __float_as_uint(s1);
         inv              = ((u & 0x7fffffu) == 0x7fffffu) ? __uint_as_float(0x7f000000u - u) : inv;
-    } else {
-        asm volatile("" : "+v"(q)); // keep the general case behind its branch
-        inv = 1.0f / sqrtf(q);
+        if (__ballot(!(fabsf(q - 1.0f) < 0.0625f)) != 0ull) {
+            asm volatile("" : "+v"(q)); // keep the general case behind its branch
+            if (!(fabsf(q - 1.0f) < 0.0625f))
+                inv = 1.0f / sqrtf(q);
+        }
     }
 #endif
     return inv;
@@ -131,7 +135,8 @@ template <bool TINY_OK = false> __device__ __forceinline__ float div_by_recip(fl
 {
     const float q = a * y;
     const float r = fmaf(-b, q, a);
-    float c       = copysignf(fmaf(r, y, q), q);
+    // (TINY_OK callers add the quotient to 1.0f: the sign of a zero quotient cannot show)
+    float c       = TINY_OK ? fmaf(r, y, q) : copysignf(fmaf(r, y, q), q);
 #ifndef RT_ABL_NOGUARD
     if (!TINY_OK && fabsf(a) < 1e-29f && a != 0.0f) { // the residual must stay a normal float: |a| > 2^-102 (CPU test: none above 3e-32)
         asm volatile("" : "+v"(a)); // keep the rare true division behind its branch
@@ -139,6 +144,14 @@ template <bool TINY_OK = false> __device__ __forceinline__ float div_by_recip(fl
     }
 #endif
     return c;
+}
+// the unguarded float form with the sign of a zero quotient kept: for callers that test the dividends
+// for the tiny range themselves (the integrator step's merged guard, rt_march.hip)
+__device__ __forceinline__ float div_by_recip_signed(float a, float b, float y)
+{
+    const float q = a * y;
+    const float r = fmaf(-b, q, a);
+    return copysignf(fmaf(r, y, q), q);
 }
 template <bool TINY_OK = false> __device__ __forceinline__ double div_by_recip(double a, double b, double y)
 {

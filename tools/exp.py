@@ -11,6 +11,7 @@ be = importlib.import_module("raytrace-miniapp_amd.backend")
 
 args = sys.argv[1:]
 check = "--check" in args
+march_only = "--march-only" in args   # skip the frequency kernel (ablated builds leave no usable records)
 cases = "ase,seed"
 if "--cases" in args:
     cases = args[args.index("--cases") + 1]
@@ -24,6 +25,8 @@ for case in cases.split(","):
     for path in libs:
         plan = be.Plan(p, lib=be.HipLibrary(path))
         plan.set_ray_grid()
+        if march_only:
+            plan.set_debug(1)
         plans.append(plan)
     best = [(1e9, 1e9)] * len(libs)
     for rnd in range(5):
