@@ -3,18 +3,19 @@
 #   pass 1: --kernel-trace --stats          -> per-kernel time
 #   pass 2: --pmc FETCH_SIZE                -> HBM read side  (TCC, 3 slots)
 #   pass 3: --pmc WRITE_SIZE                -> HBM write side (TCC, 2 slots)
-#   pass 4: --pmc SQ counters               -> VALU utilisation / occupancy
+#   pass 4/5: --pmc SQ counters             -> instruction counts / issue utilisation, shader clock
+#   pass 6-8: the same trace / FETCH / WRITE passes for BASELINE config 5 (--workload config5)
 # PMC passes are separate runs with no tracing domains beside --kernel-trace
 # (MI355X_MICROARCH.md "HBM", "rocprofv3 PMC slots").  Outputs land under
 # gpurun_out/prof_<tag>/ ; summarise with profiles/summarize.py.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 STEPS=${2:-20}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline"
+CMD="python3 bench.py --steps $STEPS --warmup 3 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/bench_trace.log" 2>&1
 echo "trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $CMD > "$OUT/bench_fetch.log" 2>&1
@@ -23,4 +24,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write
 echo "write done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o pmc -- $CMD > "$OUT/bench_sq.log" 2>&1 || echo "sq pass failed"
 echo "sq done"
-python3 profiles/summarize.py "$OUT" "$TAG" > "$OUT/summary.json"; tail -5 "$OUT/bench_trace.log"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM --output-format csv -d "$OUT/pmc_sq2" -o pmc -- $CMD > "$OUT/bench_sq2.log" 2>&1 || echo "sq2 pass failed"
+echo "sq2 done"
+C5="python3 bench.py --workload config5 --steps 3 --warmup 1 --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_trace" -o trace -- $C5 > "$OUT/c5_trace.log" 2>&1 || echo "c5 trace failed"
+echo "c5 trace done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/c5_fetch" -o pmc -- $C5 > "$OUT/c5_fetch.log" 2>&1 || echo "c5 fetch failed"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/c5_write" -o pmc -- $C5 > "$OUT/c5_write.log" 2>&1 || echo "c5 write failed"
+echo "c5 pmc done"
+python3 profiles/summarize.py "$OUT" "$TAG" > "$OUT/summary.json"; tail -3 "$OUT/bench_trace.log"

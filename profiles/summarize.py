@@ -29,8 +29,8 @@ def which(name):
     return None
 
 
-def kernel_stats(root, out_csv):
-    f = find(Path(root) / "trace", "*kernel_stats.csv")
+def kernel_stats(root, out_csv, sub="trace"):
+    f = find(Path(root) / sub, "*kernel_stats.csv")
     if f is None:
         return {}
     rows = list(csv.DictReader(open(f)))
@@ -86,6 +86,35 @@ def main():
         hbm[k] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     out["hbm"] = hbm
     out["hbm_note"] = "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; separate --pmc passes"
+    # second SQ pass: instruction mix, and the shader clock from GRBM_GUI_ACTIVE (summed over the 8 XCDs)
+    sq2 = pmc(root, "pmc_sq2")
+    out["pmc_sq2"] = sq2
+    kt = out["kernel_trace"]
+    clocks = []
+    for k in KERNELS:
+        gui = sq2.get(k, {}).get("avg", {}).get("GRBM_GUI_ACTIVE")
+        if gui and k in kt:
+            clocks.append(gui / 8.0 / (kt[k]["avg_ns"] * 1e-9))
+    if clocks:
+        out["shader_clock_hz"] = sum(clocks) / len(clocks)
+    # BASELINE config 5 (bench.py --workload config5): kernel times and HBM bytes per step
+    c5t = kernel_stats(root, here / f"{tag}_config5_kernel_stats.csv", "c5_trace")
+    c5f, c5w = pmc(root, "c5_fetch"), pmc(root, "c5_write")
+    if c5t:
+        c5 = {"kernel_trace": c5t, "kernels": {}}
+        tot = 0.0
+        for k in KERNELS:
+            fs = c5f.get(k, {}).get("avg", {}).get("FETCH_SIZE")
+            ws = c5w.get(k, {}).get("avg", {}).get("WRITE_SIZE")
+            if fs is None or ws is None:
+                continue
+            rd, wr = fs * 1024.0 * 2.0, ws * 1024.0
+            c5["kernels"][k] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr,
+                                "hbm_bytes_per_launch": rd + wr}
+            tot += rd + wr
+        if c5["kernels"]:
+            c5["hbm_bytes_per_step"] = tot
+        out["config5"] = c5
     (here / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
     if hbm:
         (here / "traffic_latest.json").write_text(json.dumps(
