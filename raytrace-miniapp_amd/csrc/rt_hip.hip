@@ -78,8 +78,8 @@ struct ArenaBuilder {
 // ray list (16 B/ray), the tangents and the march records (96 B/ray) are hundreds of MB per
 // call and hipMalloc/hipFree of them costs milliseconds.  Freed blocks are parked per device
 // (at most POOL_MAX_BLOCKS, POOL_MAX_BYTES) and handed out again best-fit.
-constexpr size_t POOL_MAX_BLOCKS = 8;
-constexpr size_t POOL_MIN_BYTES  = (size_t) 1 << 20; // small blocks are not worth parking
+constexpr size_t POOL_MAX_BLOCKS = 32;
+constexpr size_t POOL_MIN_BYTES  = 0; // every block is worth parking: hipMalloc + hipFree cost ~0.1 ms a pair
 size_t pool_max_bytes()
 {
     static const size_t cap = [] {
@@ -548,13 +548,13 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
     pool_free(p->device, p->rec);
     (void) hipFree(p->path_dev);
     (void) hipFree(p->path_err);
-    (void) hipFree(p->arena);
+    pool_free(p->device, p->arena);
     pool_free(p->device, p->rays_dev);
-    (void) hipFree(p->grid_dev);
+    pool_free(p->device, p->grid_dev);
     (void) hipFree(p->seedtab_dev);
-    (void) hipFree(p->image_own);
-    (void) hipFree(p->iang_own);
-    (void) hipFree(p->ctl);
+    pool_free(p->device, p->image_own);
+    pool_free(p->device, p->iang_own);
+    pool_free(p->device, p->ctl);
     (void) hipFree(p->probe);
     (void) hipFree(p->bad_dev);
     delete p;
@@ -595,14 +595,36 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     rt_hip_plan *p = new rt_hip_plan();
     p->t_created   = std::chrono::steady_clock::now();
     p->device      = device;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) {
-        delete p;
-        return fail_hip(e, "hipGetDeviceProperties", __LINE__);
+    {
+        // the CU count of a device does not change: asked once (hipGetDeviceProperties costs ~0.3 ms a call)
+        static std::mutex mu;
+        static int cus[64] = {};
+        std::lock_guard<std::mutex> lock(mu);
+        if (device < 64 && cus[device] > 0) {
+            p->cu_count = cus[device];
+        } else {
+            int n        = 0;
+            hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
+            if (e != hipSuccess || n < 1) {
+                delete p;
+                return fail_hip(e, "hipDeviceGetAttribute(multiprocessor count)", __LINE__);
+            }
+            p->cu_count = n;
+            if (device < 64)
+                cus[device] = n;
+        }
     }
-    p->cu_count = prop.multiProcessorCount;
 
+    static const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap    = [&](const char *what) {
+        if (timing) {
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "    plan_create %-18s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+            t_prev = now;
+        }
+    };
+    lap("device");
     // ---- pack the arena -------------------------------------------------
     ArenaBuilder ab;
     std::vector<rt::DevGain> dg((size_t) N);
@@ -718,6 +740,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         return fail_arg("rt_hip_plan_create: non-finite index of refraction");
     }
     const size_t off_blob = ab.put(blob.data(), blob.size());
+    lap("pack");
 
 #define PLAN_TRY(expr)                                   \
     do {                                                 \
@@ -729,13 +752,14 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     } while (0)
 
     p->arena_bytes = align_up(ab.host.size(), 256);
-    PLAN_TRY(dev_malloc((void **) &p->arena, p->arena_bytes));
+    PLAN_TRY(pool_alloc(device, (void **) &p->arena, p->arena_bytes));
     unsigned char *A = p->arena;
     for (int i = 1; i < N; i++) {
         dg[(size_t) i].gv = reinterpret_cast<const float *>(A + off_gv[(size_t) i]);
     }
     memcpy(ab.host.data() + off_gain, dg.data(), sizeof(rt::DevGain) * (size_t) N);
     PLAN_TRY(hipMemcpy(p->arena, ab.host.data(), ab.host.size(), hipMemcpyHostToDevice));
+    lap("alloc + upload");
 
     rt::DevParams &P = p->P;
     P.N        = N;
@@ -787,7 +811,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     p->beam_b.assign(beam->b, beam->b + beam->nb);
     p->n_image = (size_t) beam->nx * (size_t) beam->ny * (size_t) beam->nv;
     p->n_iang  = (size_t) beam->na * (size_t) beam->nb;
-    PLAN_TRY(hipMalloc((void **) &p->ctl, sizeof(rt::DevCtl)));
+    PLAN_TRY(pool_alloc(device, (void **) &p->ctl, sizeof(rt::DevCtl)));
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipEventCreate(&p->evm));
@@ -796,15 +820,24 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     P.c_h1       = 0.5f * 0.1f;
     P.c_h3       = 0.5f * 0.05f;
     {
-        // largest finite |lineshape value| of the planes the frequency pass reads
+        // largest finite |lineshape value| of the planes the emission-mode frequency pass reads (integer
+        // maximum of the magnitude bits: non-negative floats order like their bit patterns, and the loop
+        // vectorises)
         float wmax = 0.0f;
-        for (int i = 1; i < N; i++) {
-            const size_t n = (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K;
-            for (size_t c = 0; c < n; c++) {
-                const float a = fabsf(gain[i].gv[c]);
-                if (a > wmax && a <= FLT_MAX)
-                    wmax = a;
+        if (use_emis) {
+            uint32_t umax = 0;
+            for (int i = 1; i < N; i++) {
+                const size_t n    = (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K;
+                const uint32_t *u = reinterpret_cast<const uint32_t *>(gain[i].gv);
+                uint32_t m        = 0;
+                for (size_t c = 0; c < n; c++) {
+                    uint32_t a = u[c] & 0x7fffffffu;
+                    a          = a < 0x7f800000u ? a : 0u; // inf and NaN do not count
+                    m          = a > m ? a : m;
+                }
+                umax = m > umax ? m : umax;
             }
+            memcpy(&wmax, &umax, sizeof(wmax));
         }
         P.gs_cap = wmax > 0.0f ? 708.0f / wmax : FLT_MAX;
         if (!(P.gs_cap <= FLT_MAX))
@@ -812,6 +845,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     }
     P.ctl = p->ctl;
     *out  = p;
+    lap("rest");
     return RT_OK;
 }
 
@@ -892,7 +926,7 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
         return fail_arg("rt_hip_plan_set_ray_grid: ray range outside the grid");
     HIP_TRY(hipSetDevice(p->device));
     plan_quiesce(p);
-    (void) hipFree(p->grid_dev);
+    pool_free(p->device, p->grid_dev);
     p->grid_dev     = nullptr;
     (void) hipFree(p->seedtab_dev);
     p->seedtab_dev  = nullptr;
@@ -902,7 +936,7 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     memcpy(h.data() + ngx, gy, sizeof(double) * (size_t) ngy);
     memcpy(h.data() + ngx + ngy, ga, sizeof(double) * (size_t) nga);
     memcpy(h.data() + ngx + ngy + nga, gb, sizeof(double) * (size_t) ngb);
-    HIP_TRY(hipMalloc((void **) &p->grid_dev, nn * sizeof(double)));
+    HIP_TRY(pool_alloc(p->device, (void **) &p->grid_dev, nn * sizeof(double)));
     HIP_TRY(hipMemcpy(p->grid_dev, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
     // Helper.h:409-410: tanf(1e-3f * ray.a) depends only on the grid value: nga + ngb
     // evaluations on the host, with the same libm the CPU loop uses
@@ -1088,12 +1122,12 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (!image_dev) {
         if (!p->image_own)
-            HIP_TRY(dev_malloc((void **) &p->image_own, p->n_image * sizeof(double)));
+            HIP_TRY(pool_alloc(p->device, (void **) &p->image_own, p->n_image * sizeof(double)));
         image_dev = p->image_own;
     }
     if (!iang_dev) {
         if (!p->iang_own)
-            HIP_TRY(dev_malloc((void **) &p->iang_own, p->n_iang * sizeof(double)));
+            HIP_TRY(pool_alloc(p->device, (void **) &p->iang_own, p->n_iang * sizeof(double)));
         iang_dev = p->iang_own;
     }
     int rc = plan_prepare_probe(p);
@@ -1287,31 +1321,49 @@ static bool guess_ray_grid(const rt_ray *rays, size_t n, GridGuess &G)
     return true;
 }
 
-// every ray of the list against the grid, on up to `threads` host threads
+// every ray of the list against the grid, on up to `threads` host threads.  A ray is two 64-bit words,
+// (x, y) and (a, b); a run of nb rays shares the first word and the a half of the second, so the
+// inner loop is two integer compares per ray over a stream the memory system prefetches: ~1 ms for the
+// 102 MB of a 6.4 M-ray list on 16 threads, hidden behind the kernels it runs beside.
 static bool verify_ray_grid(const rt_ray *rays, size_t n, const GridGuess &G, unsigned threads)
 {
     const size_t nb = G.g[3].size(), na = G.g[2].size(), ny = G.g[1].size();
-    std::vector<float> fx(G.g[0].begin(), G.g[0].end()), fy(G.g[1].begin(), G.g[1].end());
-    std::vector<float> fa(G.g[2].begin(), G.g[2].end()), fb(G.g[3].begin(), G.g[3].end());
+    auto bits = [](double v) {
+        const float f = (float) v;
+        uint32_t u;
+        memcpy(&u, &f, sizeof(u));
+        return (uint64_t) u;
+    };
+    std::vector<uint64_t> bx(G.g[0].size()), by(ny), ba(na), bb(nb);
+    for (size_t i = 0; i < bx.size(); i++)
+        bx[i] = bits(G.g[0][i]);
+    for (size_t i = 0; i < ny; i++)
+        by[i] = bits(G.g[1][i]) << 32;
+    for (size_t i = 0; i < na; i++)
+        ba[i] = bits(G.g[2][i]);
+    for (size_t i = 0; i < nb; i++)
+        bb[i] = bits(G.g[3][i]) << 32;
     const size_t rows = n / nb; // runs of nb rays that differ only in b
     threads           = threads < 1 ? 1 : threads;
-    if (rows < 4 * (size_t) threads)
+    if (n < (size_t) 1 << 18)
         threads = 1;
     std::atomic<bool> ok(true);
     auto work = [&](size_t r0, size_t r1) {
-        for (size_t r = r0; r < r1 && ok.load(std::memory_order_relaxed); r++) {
+        uint64_t diff = 0;
+        for (size_t r = r0; r < r1; r++) {
             const size_t k = r % na, j = (r / na) % ny, i = r / (na * ny);
-            const rt_ray want = { fx[i], fy[j], fa[k], 0.0f };
-            const rt_ray *row = rays + r * nb;
-            bool good         = true;
+            const uint64_t xy = bx[i] | by[j], a = ba[k];
+            uint64_t w[2];
+            const unsigned char *row = reinterpret_cast<const unsigned char *>(rays + r * nb);
             for (size_t m = 0; m < nb; m++) {
-                rt_ray w = want;
-                w.b      = fb[m];
-                good &= memcmp(&row[m], &w, sizeof(rt_ray)) == 0;
+                memcpy(w, row + 16 * m, 16);
+                diff |= (w[0] ^ xy) | (w[1] ^ (a | bb[m]));
             }
-            if (!good)
-                ok.store(false, std::memory_order_relaxed);
+            if ((r & 1023) == 1023 && (diff != 0 || !ok.load(std::memory_order_relaxed)))
+                break;
         }
+        if (diff != 0)
+            ok.store(false, std::memory_order_relaxed);
     };
     if (threads == 1) {
         work(0, rows);
@@ -1349,23 +1401,38 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
         return fail_arg("rt_hip_image_loop: NULL ray list");
     if (n_rays > MAX_LIST_RAYS)
         return fail_arg("rt_hip_image_loop: 2^32 - 512 rays or more: split the call");
+    // RT_HIP_TIMING=1: wall-clock split of this call on stderr (diagnostic)
+    static const bool timing = getenv("RT_HIP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap    = [&](const char *what) {
+        if (timing) {
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "  rt_hip_image_loop %-22s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+            t_prev = now;
+        }
+    };
     rt_hip_plan *p = nullptr;
     int rc         = rt_hip_plan_create(&p, device, N, beam, gain, seed, method, scale);
     if (rc != RT_OK)
         return rc;
+    lap("plan_create");
     hipStream_t q = lease_queue(device);
     // A list that is a whole tensor grid (what create_image builds) is not uploaded: the device
     // generates the rays while host threads check the list against the grid, ray by ray.
     GridGuess G;
     bool as_grid = n_rays >= (1u << 16) && !getenv("RT_HIP_NO_GRID_DETECT") && guess_ray_grid(rays, n_rays, G);
+    lap("guess grid");
     if (as_grid) {
         rc = plan_set_guessed_grid(p, G, 0, (int64_t) n_rays);
+        lap("set_ray_grid");
         if (rc == RT_OK)
             rc = rt_hip_plan_run(p, q, nullptr, nullptr); // asynchronous
-        if (rc == RT_OK && !verify_ray_grid(rays, n_rays, G, host_threads(8))) {
+        lap("run (launch)");
+        if (rc == RT_OK && !verify_ray_grid(rays, n_rays, G, host_threads(16))) {
             as_grid = false; // not that grid after all: the speculative result is discarded below
             plan_quiesce(p);
         }
+        lap("verify list");
     }
     if (rc == RT_OK && !as_grid) {
         rc = plan_set_rays_deferred(p, rays, n_rays);
@@ -1374,8 +1441,10 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
     }
     if (rc == RT_OK)
         rc = rt_hip_plan_fetch(p, image, I_ang, failure_code, failed_rays, max_failed, n_failed, stats);
+    lap("fetch (wait + D2H)");
     rt_hip_plan_destroy(p); // waits for whatever is still in flight
     release_queue(device, q);
+    lap("destroy");
     return rc;
 }
 
@@ -1515,7 +1584,7 @@ int rt_hip_multi_last_mode(void) { return g_multi_mode; }
 int rt_hip_ray_list_grid_dims(const rt_ray *rays, size_t n_rays, int dims[4])
 {
     GridGuess G;
-    if (!rays || !dims || !guess_ray_grid(rays, n_rays, G) || !verify_ray_grid(rays, n_rays, G, host_threads(8)))
+    if (!rays || !dims || !guess_ray_grid(rays, n_rays, G) || !verify_ray_grid(rays, n_rays, G, host_threads(16)))
         return 0;
     for (int i = 0; i < 4; i++)
         dims[i] = (int) G.g[i].size();
