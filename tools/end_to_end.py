@@ -18,5 +18,5 @@ for name, p in cases.items():
         g = []
         for i in range(3):
             t0 = time.perf_counter(); plan.run(); o2 = plan.fetch(); g.append((time.perf_counter() - t0) * 1e3)
-    print(f"{name:20s} rays {len(rays):9d}  image_loop (ray list, 16 B/ray upload) {min(t):8.2f} ms   "
+    print(f"{name:20s} rays {len(rays):9d}  image_loop (host ray list handed over)    {min(t):8.2f} ms   "
           f"plan.run+fetch (device ray grid, tables resident) {min(g):7.2f} ms   kernels {out['stats']['kernel_ms']:.2f} ms")
