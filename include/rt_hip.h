@@ -215,6 +215,13 @@ int rt_hip_plan_kernel_ms(rt_hip_plan *plan, float *ms);
  * deposit kernel (rt_freq_kernel) of the last run. */
 int rt_hip_plan_kernel_times(rt_hip_plan *plan, float *march_ms, float *freq_ms);
 
+/* Timing many back-to-back runs without waiting for each: keep the event triples of the last n_runs runs
+ * (1 <= n_runs <= 4096); rt_hip_plan_ring_times waits for the last run and returns the kernel durations of
+ * the most recent runs, oldest first (at most max_runs of them; *n_runs = how many).  Without a ring a plan
+ * keeps the events of its last run only (rt_hip_plan_kernel_times). */
+int rt_hip_plan_set_timing_ring(rt_hip_plan *plan, int n_runs);
+int rt_hip_plan_ring_times(rt_hip_plan *plan, float *march_ms, float *freq_ms, int max_runs, int *n_runs);
+
 /* Device pointers of the plan's own output buffers (for RCCL / torch views). */
 double *rt_hip_plan_image_ptr(rt_hip_plan *plan);
 double *rt_hip_plan_iang_ptr(rt_hip_plan *plan);

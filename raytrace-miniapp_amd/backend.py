@@ -189,6 +189,24 @@ class Plan:
                       "rt_hip_plan_kernel_times")
         return float(a.value), float(f.value)
 
+    def set_timing_ring(self, n_runs: int) -> "Plan":
+        """Keep the kernel-event triples of the last n_runs runs (include/rt_hip.h)."""
+        self.hl.check(self.hl.lib.rt_hip_plan_set_timing_ring(self._h, int(n_runs)), "rt_hip_plan_set_timing_ring")
+        self._ring = int(n_runs)
+        return self
+
+    def ring_times(self) -> list:
+        """[(march_ms, freq_ms)] of the most recent runs, oldest first (waits for the last run)."""
+        n = getattr(self, "_ring", 0)
+        if n < 1:
+            return []
+        a = np.zeros(n, np.float32)
+        f = np.zeros(n, np.float32)
+        got = C.c_int(0)
+        self.hl.check(self.hl.lib.rt_hip_plan_ring_times(self._h, cabi._fp(a), cabi._fp(f), n, C.byref(got)),
+                      "rt_hip_plan_ring_times")
+        return [(float(a[i]), float(f[i])) for i in range(got.value)]
+
     def fetch_probe(self) -> dict:
         n = self.n_rays
         S = (self.problem.N - 1) * cabi.RT_N_SUB

@@ -245,6 +245,10 @@ struct rt_hip_plan {
     hipStream_t last_stream = nullptr;
     double *last_image = nullptr, *last_iang = nullptr;
     bool ran = false;
+    // timing ring (rt_hip_plan_set_timing_ring): event triples of the last runs, so that a caller can time
+    // many back-to-back runs without waiting for each; ev0 / evm / ev1 above are the current run's triple
+    std::vector<hipEvent_t> ring; // 3 per slot
+    unsigned long long runs = 0;
     bool repeated = false; // the checking repeat of the frequency pass has run for the last run
     unsigned char *bad_dev = nullptr; // failing-ray marks of the checking repeat (plan_repeat_checked)
     size_t bad_rays        = 0;
@@ -538,12 +542,16 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         return;
     (void) hipSetDevice(p->device);
     plan_quiesce(p); // kernels of an unfetched (or failed) run may still use the buffers parked below
-    if (p->ev0)
-        (void) hipEventDestroy(p->ev0);
-    if (p->ev1)
-        (void) hipEventDestroy(p->ev1);
-    if (p->evm)
-        (void) hipEventDestroy(p->evm);
+    if (p->ring.empty()) {
+        if (p->ev0)
+            (void) hipEventDestroy(p->ev0);
+        if (p->ev1)
+            (void) hipEventDestroy(p->ev1);
+        if (p->evm)
+            (void) hipEventDestroy(p->evm);
+    }
+    for (hipEvent_t e : p->ring) // (with a ring, ev0 / evm / ev1 alias one of its slots)
+        (void) hipEventDestroy(e);
     pool_free(p->device, p->tan_dev);
     pool_free(p->device, p->rec);
     (void) hipFree(p->path_dev);
@@ -1142,6 +1150,13 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     p->P.image   = image_dev;
     p->P.iang    = iang_dev;
     p->P.n_tiles = (unsigned) ((p->n_rays + rt::WAVE - 1) / rt::WAVE);
+    if (!p->ring.empty()) {
+        const size_t slot = (size_t) (p->runs % (p->ring.size() / 3)) * 3;
+        p->ev0            = p->ring[slot];
+        p->evm            = p->ring[slot + 1];
+        p->ev1            = p->ring[slot + 2];
+    }
+    p->runs++;
 
     rc = plan_run_split(p, stream);
     if (rc != RT_OK)
@@ -1211,6 +1226,53 @@ int rt_hip_plan_kernel_ms(rt_hip_plan *p, float *ms)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev1));
     HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return RT_OK;
+}
+
+int rt_hip_plan_set_timing_ring(rt_hip_plan *p, int n_runs)
+{
+    if (!p || n_runs < 1 || n_runs > 4096)
+        return fail_arg("rt_hip_plan_set_timing_ring: 1 .. 4096 runs");
+    HIP_TRY(hipSetDevice(p->device));
+    plan_quiesce(p);
+    if (p->ring.empty()) { // the plan's own triple becomes slot 0
+        p->ring = { p->ev0, p->evm, p->ev1 };
+    }
+    while (p->ring.size() < (size_t) n_runs * 3) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        p->ring.push_back(e);
+    }
+    while (p->ring.size() > (size_t) n_runs * 3) {
+        (void) hipEventDestroy(p->ring.back());
+        p->ring.pop_back();
+    }
+    p->ev0  = p->ring[0];
+    p->evm  = p->ring[1];
+    p->ev1  = p->ring[2];
+    p->runs = 0;
+    p->ran  = false;
+    return RT_OK;
+}
+
+int rt_hip_plan_ring_times(rt_hip_plan *p, float *march_ms, float *freq_ms, int max_runs, int *n_runs)
+{
+    if (!p || !march_ms || !freq_ms || !n_runs || max_runs < 0)
+        return fail_arg("rt_hip_plan_ring_times: bad argument");
+    *n_runs = 0;
+    if (!p->ran || p->ring.empty())
+        return RT_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->last_stream));
+    const unsigned long long slots = p->ring.size() / 3;
+    const unsigned long long have  = p->runs < slots ? p->runs : slots;
+    const unsigned long long take  = have < (unsigned long long) max_runs ? have : (unsigned long long) max_runs;
+    for (unsigned long long i = 0; i < take; i++) { // oldest first
+        const size_t slot = (size_t) ((p->runs - take + i) % slots) * 3;
+        HIP_TRY(hipEventElapsedTime(&march_ms[i], p->ring[slot], p->ring[slot + 1]));
+        HIP_TRY(hipEventElapsedTime(&freq_ms[i], p->ring[slot + 1], p->ring[slot + 2]));
+    }
+    *n_runs = (int) take;
     return RT_OK;
 }
 

@@ -84,3 +84,18 @@ def test_pool_trim_and_concurrent_image_loops(hip, ase_small):
     hip.HipLibrary.get().lib.rt_hip_pool_trim()
     again = hip.image_loop(ase_small)
     assert rel_l2(again["image"], want["image"]) < 1e-12
+
+
+def test_timing_ring_keeps_the_last_runs(hip, ase_small):
+    """rt_hip_plan_set_timing_ring: back-to-back runs are timed without waiting for each (bench.py)."""
+    with hip.Plan(ase_small) as plan:
+        plan.set_ray_grid().set_timing_ring(3)
+        assert plan.ring_times() == []
+        for _ in range(5):
+            plan.run()
+        t = plan.ring_times()
+        assert len(t) == 3 and all(0.0 < m < 50.0 and 0.0 < f < 50.0 for m, f in t)
+        last = plan.kernel_times()
+        assert abs(last[0] - t[-1][0]) < 1e-6 and abs(last[1] - t[-1][1]) < 1e-6
+        out = plan.fetch()
+        assert out["failure_code"] == 0 and out["stats"]["cell_steps"] == 4768067
