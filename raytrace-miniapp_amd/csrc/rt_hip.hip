@@ -427,10 +427,13 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     unsigned long long want = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
     unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
     const unsigned grid     = (unsigned) (want < cap ? want : cap);
-    // rays reserved per counter fetch: big enough to amortise the atomic, small enough
-    // that the last chunks balance (about 8 chunks per wave)
+    // rays reserved per counter fetch: big enough to amortise the atomic, small enough that the last
+    // chunks balance (about 8 chunks per wave), within 64 ... 192 -- swept on the stand-in and on its
+    // strong-scaling shards (tools/shard_sweep2.py): a whole 64-ray refill per fetch is the least that
+    // pays (798 K rays: 0.88 ms at 16, 0.55 at 32, 0.44 at 64, 0.60 at 96), 64 ... 192 is flat at 6.4 M
+    // rays (2.02 ms; 2.66 at 32, 2.05 at 256)
     unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
-    ch                    = ch < 16 ? 16 : (ch > 512 ? 512 : ch);
+    ch                    = ch < 64 ? 64 : (ch > 192 ? 192 : ch);
     p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
     p->P.chunk = env_unsigned("RT_HIP_MARCH_CHUNK", p->P.chunk, 1, 1u << 20); // tuning
     // lanes that must wait for block [A] of the march before it runs (swept 1 ... 40 on the 6.4 M-ray
@@ -474,7 +477,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         }
         if (n_launch > 1) { // rays reserved per counter fetch, for this slice
             unsigned long long cs = (e - b) / ((unsigned long long) grid * (bthr / 64) * 8);
-            cs                    = cs < 16 ? 16 : (cs > 512 ? 512 : cs);
+            cs                    = cs < 64 ? 64 : (cs > 192 ? 192 : cs);
             p->P.chunk            = (unsigned) ((cs + 15) / 16 * 16);
         }
         p->P.ray_begin = (unsigned) b;
