@@ -168,6 +168,13 @@ int rt_hip_ray_list_grid_dims(const rt_ray *rays, size_t n_rays, int dims[4]);
  * 2 = ray chunks + sum-reduce, 0 = none yet.  (Diagnostics and tests.) */
 int rt_hip_multi_last_mode(void);
 
+/* List-mode launch tangents (Helper.h:409-410) are computed on the device by a restatement of glibc
+ * 2.35's float tanf; once per process that restatement is compared with the host's tanf on 8192 angles.
+ * 1: they agree, the device computes the tangents; 2: they do not (another libm; or RT_HIP_TAN_ON_HOST
+ * set): the host's tanf computes them on host threads, so that every ray starts as RayTraceImageCPULoop on
+ * this host starts it.  Ray grids always use the host's tanf (na + nb values). */
+int rt_hip_host_libm_mode(int device);
+
 /* Device allocations -- never data -- are kept across calls (ray lists, tangents, march records;
  * Readme.txt:43 forbids caching data only).  This returns every parked block of every device to the
  * driver; RT_HIP_POOL_MAX_MB in the environment caps what may be parked (default 32768). */

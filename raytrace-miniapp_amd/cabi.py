@@ -138,6 +138,8 @@ def declare_hip_api(lib: C.CDLL) -> None:
     lib.rt_hip_multi_last_mode.restype = C.c_int
     lib.rt_hip_ray_list_grid_dims.argtypes = [P(RtRay), C.c_size_t, P(C.c_int * 4)]
     lib.rt_hip_ray_list_grid_dims.restype = C.c_int
+    lib.rt_hip_host_libm_mode.argtypes = [C.c_int]
+    lib.rt_hip_host_libm_mode.restype = C.c_int
     lib.rt_hip_pool_trim.argtypes = []
     lib.rt_hip_pool_trim.restype = None
     lib.rt_hip_plan_create.argtypes = [P(vp), C.c_int, C.c_int, P(RtBeam), P(RtGain), P(RtSeed),
@@ -188,7 +190,7 @@ def declare_hip_api(lib: C.CDLL) -> None:
 #: every symbol the header declares -- checked by tests/test_cabi_exports.py
 HIP_API_SYMBOLS = [
     "rt_hip_device_count", "rt_hip_last_error", "rt_hip_selftest", "rt_hip_image_loop", "rt_hip_multi_image_loop",
-    "rt_hip_multi_last_mode", "rt_hip_ray_list_grid_dims", "rt_hip_pool_trim", "rt_hip_plan_create",
+    "rt_hip_multi_last_mode", "rt_hip_ray_list_grid_dims", "rt_hip_host_libm_mode", "rt_hip_pool_trim", "rt_hip_plan_create",
     "rt_hip_plan_set_rays", "rt_hip_plan_set_ray_grid", "rt_hip_plan_run", "rt_hip_plan_fetch",
     "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_set_timing_ring", "rt_hip_plan_ring_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
     "rt_hip_plan_fetch_probe", "rt_hip_plan_set_exact_emission", "rt_hip_plan_set_step_factor", "rt_hip_plan_enable_path",

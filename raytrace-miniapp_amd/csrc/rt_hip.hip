@@ -342,6 +342,81 @@ static void plan_quiesce(rt_hip_plan *p)
     }
 }
 
+// ---- list-mode launch tangents and the host's libm ------------------------------------------------
+// rt_tan_kernel restates the float tanf of glibc 2.35 (rt_march.hip).  Whether THIS host's tanf is that
+// routine is probed once per process: 8192 angles from 1e-3 mrad to 1.37 rad, both signs, device against
+// host, bit for bit.  If they differ anywhere (another libm), list-mode tangents are computed by the
+// host's tanf on host threads and uploaded -- slower (two libm calls per ray), but the march then starts
+// every ray exactly as RayTraceImageCPULoop on this host does.  (Grid mode always uses the host's tanf.)
+static unsigned host_threads(unsigned cap); // (defined with the ray-grid recognition below)
+static std::atomic<int> g_tan_mode(0); // 0 unknown, 1 device restatement == host tanf, 2 host tangents
+
+static void host_tangents(const rt_ray *rays, size_t n, float *sxy)
+{
+    const unsigned threads = n >= (1u << 16) ? host_threads(16) : 1;
+    auto work = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            sxy[2 * i]     = tanf(1e-3f * rays[i].a); // Helper.h:409-410
+            sxy[2 * i + 1] = tanf(1e-3f * rays[i].b);
+        }
+    };
+    if (threads == 1) {
+        work(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++)
+        th.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+    for (auto &t : th)
+        t.join();
+}
+
+static int tan_mode(int device)
+{
+    int m = g_tan_mode.load();
+    if (m != 0)
+        return m;
+    if (getenv("RT_HIP_TAN_ON_HOST")) {
+        g_tan_mode.store(2);
+        return 2;
+    }
+    const size_t n = 8192;
+    std::vector<rt_ray> r(n);
+    for (size_t i = 0; i < n; i++) {
+        // geometric ladder of magnitudes with a wobble in the low bits, alternating signs
+        const double mag = 1e-3 * pow(1.37e6, (double) (i / 2) / (double) (n / 2 - 1)); // mrad: 1e-3 ... 1370
+        const float a    = (float) (mag * (1.0 + 1e-4 * (double) ((i * 2654435761u) & 1023u)));
+        r[i]             = { 0.0f, 0.0f, (i & 1) ? -a : a, (i & 1) ? a : -a };
+    }
+    rt_ray *d_r  = nullptr;
+    float *d_sxy = nullptr;
+    std::vector<float> got(2 * n), want(2 * n);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipMalloc((void **) &d_r, n * sizeof(rt_ray));
+    if (e == hipSuccess)
+        e = hipMalloc((void **) &d_sxy, 2 * n * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(d_r, r.data(), n * sizeof(rt_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt::rt_tan_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, nullptr, d_r,
+                           (unsigned long long) n, d_sxy);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(got.data(), d_sxy, 2 * n * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d_r);
+    (void) hipFree(d_sxy);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        return 1; // the probe could not run: the caller's own HIP calls will report what is wrong
+    }
+    host_tangents(r.data(), n, want.data());
+    m = memcmp(got.data(), want.data(), 2 * n * sizeof(float)) == 0 ? 1 : 2;
+    g_tan_mode.store(m);
+    return m;
+}
+
 static int launch_freq_any(rt_hip_plan *p, hipStream_t stream)
 {
     const int S = p->P.L * RT_N_SUB;
@@ -471,9 +546,15 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         if (p->host_rays) {
             HIP_TRY(hipMemcpy(p->rays_dev + b, p->host_rays + b, (size_t) (e - b) * sizeof(rt_ray), hipMemcpyHostToDevice));
             // Helper.h:409-410 for every ray of the slice, at full lane occupancy, before its march
-            hipLaunchKernelGGL(rt::rt_tan_kernel, dim3((unsigned) ((e - b + 255) / 256)), dim3(256), 0, stream, p->rays_dev + b,
-                               (unsigned long long) (e - b), p->tan_dev + 2 * b);
-            HIP_TRY(hipGetLastError());
+            if (tan_mode(p->device) == 2) { // this host's tanf is not the restated one: its own values
+                std::vector<float> h((size_t) (e - b) * 2);
+                host_tangents(p->host_rays + b, (size_t) (e - b), h.data());
+                HIP_TRY(hipMemcpy(p->tan_dev + 2 * b, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            } else {
+                hipLaunchKernelGGL(rt::rt_tan_kernel, dim3((unsigned) ((e - b + 255) / 256)), dim3(256), 0, stream,
+                                   p->rays_dev + b, (unsigned long long) (e - b), p->tan_dev + 2 * b);
+                HIP_TRY(hipGetLastError());
+            }
         }
         if (n_launch > 1) { // rays reserved per counter fetch, for this slice
             unsigned long long cs = (e - b) / ((unsigned long long) grid * (bthr / 64) * 8);
@@ -908,11 +989,17 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
     if (n_rays) {
         // Helper.h:409-410 for every ray, at full lane occupancy, before the march
         HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, n_rays * 2 * sizeof(float)));
-        const unsigned blocks = (unsigned) ((n_rays + 255) / 256);
-        hipLaunchKernelGGL(rt::rt_tan_kernel, dim3(blocks), dim3(256), 0, nullptr, p->rays_dev,
-                           (unsigned long long) n_rays, p->tan_dev);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
+        if (tan_mode(p->device) == 2) {
+            std::vector<float> h(n_rays * 2);
+            host_tangents(rays, n_rays, h.data());
+            HIP_TRY(hipMemcpy(p->tan_dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            const unsigned blocks = (unsigned) ((n_rays + 255) / 256);
+            hipLaunchKernelGGL(rt::rt_tan_kernel, dim3(blocks), dim3(256), 0, nullptr, p->rays_dev,
+                               (unsigned long long) n_rays, p->tan_dev);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
     }
     p->P.exclusive  = 0;
     p->P.rays       = {};
@@ -1645,6 +1732,8 @@ extern "C" __global__ void __launch_bounds__(256) rt_interleave_kernel(const dou
 } // namespace rt
 
 int rt_hip_multi_last_mode(void) { return g_multi_mode; }
+
+int rt_hip_host_libm_mode(int device) { return tan_mode(device); }
 
 int rt_hip_ray_list_grid_dims(const rt_ray *rays, size_t n_rays, int dims[4])
 {

@@ -99,3 +99,35 @@ def test_timing_ring_keeps_the_last_runs(hip, ase_small):
         assert abs(last[0] - t[-1][0]) < 1e-6 and abs(last[1] - t[-1][1]) < 1e-6
         out = plan.fetch()
         assert out["failure_code"] == 0 and out["stats"]["cell_steps"] == 4768067
+
+
+def test_host_libm_probe_and_host_tangent_fallback(hip, oracle, ase_small):
+    """The device restatement of tanf is probed against THIS host's tanf once per process
+    (rt_hip_host_libm_mode); on the reference platform (glibc 2.35) they agree.  The fallback -- list-mode
+    tangents from the host's tanf -- must give the same march records (run in a fresh process with
+    RT_HIP_TAN_ON_HOST=1, since the mode is decided once)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    lib = hip.HipLibrary.get().lib
+    assert lib.rt_hip_host_libm_mode(0) == 1
+    root = Path(__file__).resolve().parents[1]
+    code = (
+        "import importlib, sys, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "rt = importlib.import_module('raytrace-miniapp_amd'); be = importlib.import_module('raytrace-miniapp_amd.backend')\n"
+        "from oracle.binding import Oracle\n"
+        f"p = rt.datfile.load({str(root / 'tests' / 'golden' / 'ASE_small.dat.xz')!r})\n"
+        "rays = p.build_rays(np.arange(0, p.n_rays_total, 97, dtype=np.int64))\n"
+        "rays['a'] *= np.float32(7.3)\n"
+        "assert be.HipLibrary.get().lib.rt_hip_host_libm_mode(0) == 2\n"
+        "with be.Plan(p) as plan:\n"
+        "    plan.set_rays(rays).enable_probe().run(); out = plan.fetch(); pr = plan.fetch_probe()\n"
+        "o = Oracle().probe(p, rays, want_Iv=False)\n"
+        "for k in ('gvl', 'evl'):\n"
+        "    assert np.array_equal(pr[k].view(np.uint32), o[k].view(np.uint32))\n"
+        "assert np.array_equal(pr['ivl'], o['ivl']) and np.array_equal(pr['steps'], o['steps'])\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_HIP_TAN_ON_HOST="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
