@@ -511,7 +511,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                         return *reinterpret_cast<const Interval *>(tab + ((unsigned) off + (unsigned) u * (unsigned) sizeof(Interval)));
                     };
                     auto node_at = [&](int c) {
+#ifdef RT_ABL_NODES_GLOBAL
+                        return *reinterpret_cast<const Node *>(P.blob + ((unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node)));
+#else
                         return *reinterpret_cast<const Node *>(tab + ((unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node)));
+#endif
                     };
                     const float ya      = mirror ? fabsf(py) : py;
                     const double pxd = (double) px, yad = (double) ya;

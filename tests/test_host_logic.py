@@ -142,3 +142,41 @@ def test_ray_list_that_is_not_a_grid_is_rejected():
     neg["x"][:] = 0.0
     neg["x"][7] = -0.0                                                                    # -0.0 is not +0.0 bit for bit
     assert backend.ray_list_grid_dims(neg) is None
+
+
+# ---- bench.py / multigpu plumbing that needs no GPU ---------------------------------------------------
+def test_bench_module_does_not_touch_torch_before_it_spawns_its_ranks():
+    """`python bench.py --gpus N` starts its ranks as a torch.distributed.run child; that is only safe if
+    nothing before the spawn initialises HIP -- the module must not even import torch at import time."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = ("import sys, importlib.util\n"
+            f"spec = importlib.util.spec_from_file_location('bench', {str(root / 'bench.py')!r})\n"
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+            "assert 'torch' not in sys.modules, 'bench.py imported torch at module level'\n"
+            "assert callable(m.self_launch) and callable(m.main)\n"
+            "b = m.algorithmic_bytes(6384000, 75601675, 2, 52, False, 0, 6000, 1064)\n"
+            "assert b['march'] == 7359904800 and b['freq'] == 7967232000 and b['path'] == 15327136800\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_assembler_single_rank_is_a_view_of_its_buffer(ase_small):
+    import torch
+    mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
+    p = rt.scale_problem(ase_small, 0.05)
+    a = mg.Assembler(p, 0, 1)
+    b = p.beam
+    assert a.image.numel() == b.nx * b.ny * b.nv and a.iang.numel() == b.na * b.nb
+    a.image.fill_(2.0)
+    a.iang.fill_(3.0)
+    img, ang = a.assemble()
+    assert img.data_ptr() == a.buffer.data_ptr() and float(img.sum()) == 2.0 * a.image.numel()
+    assert float(ang.sum()) == 3.0 * a.iang.numel()
+    assert "gather" in a.describe()
+    # tiles of an uneven split: widths differ by at most one column and cover the image
+    cols = [mg.tile_columns(b.nx, r, 7) for r in range(7)]
+    assert sum(cols) == b.nx and max(cols) - min(cols) <= 1
