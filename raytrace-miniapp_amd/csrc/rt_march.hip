@@ -455,8 +455,13 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // Lane parking: block [A] costs as much as [C] but only a third of the lanes need it in any one
         // iteration; with P.park > 1 it runs only when at least that many lanes wait for it (or nobody
         // has anything else to do), the waiting lanes sit the iteration out.
+        // (the threshold follows the number of lanes that still hold a ray: a fifth of them, at most
+        // P.park -- in the tail of a launch, when a wave is down to a few rays, a fixed threshold would make
+        // each of them wait for all the others: 1024 rays took 0.34 ms with it, as long as 400 000)
         const unsigned long long want_a = __ballot(st == ST_CELL);
-        const bool do_a = (int) __popcll(want_a) >= (int) P.park || __ballot((st == ST_XSETUP) | (st == ST_STEP)) == 0ull;
+        const int n_live  = WAVE - n_idle;
+        const int park_at = (n_live + 4) / 5 < (int) P.park ? (n_live + 4) / 5 : (int) P.park;
+        const bool do_a = (int) __popcll(want_a) >= park_at || __ballot((st == ST_XSETUP) | (st == ST_STEP)) == 0ull;
         if (do_a && st == ST_CELL) {
             bool in_seg        = !escaped & (z < 0.995f * z_stop);
             if (!in_seg) {
