@@ -111,7 +111,7 @@ struct RecMeta {
 // Zeroed by a memset node before every run.
 struct DevCtl {
     unsigned int next_tile[8]; // march kernel: next unreserved ray, relative to ray_begin, per launch of a run
-    unsigned int next_tile_b; // frequency kernel: next tile
+    unsigned int next_tile_f[4]; // frequency kernel: next tile, relative to tile_begin, per launch of a run
     unsigned int failure_code;
     unsigned int n_failed;
     unsigned long long cell_steps;
@@ -148,6 +148,9 @@ struct DevParams {
     DevCtl *ctl;
     DevProbe probe;
     unsigned int n_tiles;
+    // frequency launch: tiles [tile_begin, tile_end) of 64 rays, tile counter next_tile_f[freq_id]
+    // (a run is one launch over all tiles; the range exists for experiments that split it)
+    unsigned int tile_begin, tile_end, freq_id;
     // march launch: rays [ray_begin, ray_end) of the list / grid, ray counter next_tile[launch_id]
     // (a run is one launch, or several when the ray list is still arriving from the host)
     unsigned int ray_begin, ray_end, launch_id, pad_launch;

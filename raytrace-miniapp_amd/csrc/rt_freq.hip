@@ -670,9 +670,9 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
     for (;;) {
         unsigned tile = 0;
         if (lane == 0)
-            tile = atomicAdd(&P.ctl->next_tile_b, 1u);
+            tile = P.tile_begin + atomicAdd(&P.ctl->next_tile_f[P.freq_id], 1u);
         tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
-        if (tile >= P.n_tiles)
+        if (tile >= P.tile_end)
             break;
         freq_tile<SF, EMIS>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
     }

@@ -288,7 +288,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     int per_cu = (int) ((160 * 1024) / (lds + lds_stat + 512));
     per_cu     = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     per_cu = (int) env_unsigned("RT_HIP_FREQ_WGS", (unsigned) per_cu, 1, 16); // tuning override
-    unsigned long long want = ((unsigned long long) p->P.n_tiles + 3) / 4;
+    unsigned long long want = ((unsigned long long) (p->P.tile_end - p->P.tile_begin) + 3) / 4;
     unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
     if (cap_blocks && cap > cap_blocks)
         cap = cap_blocks;
@@ -417,8 +417,12 @@ static int tan_mode(int device)
     return m;
 }
 
-static int launch_freq_any(rt_hip_plan *p, hipStream_t stream)
+static int launch_freq_any(rt_hip_plan *p, hipStream_t stream, unsigned tile_begin = 0, unsigned tile_end = ~0u,
+                           unsigned freq_id = 0)
 {
+    p->P.tile_begin = tile_begin;
+    p->P.tile_end   = tile_end < p->P.n_tiles ? tile_end : p->P.n_tiles;
+    p->P.freq_id    = freq_id;
     const int S = p->P.L * RT_N_SUB;
     if (p->P.use_emis)
         return (S == 6) ? launch_freq<6, true>(p, stream, 0) : launch_freq<0, true>(p, stream, 0);
@@ -441,7 +445,7 @@ static int plan_repeat_checked(rt_hip_plan *p)
     HIP_TRY(hipMemsetAsync(p->bad_dev, 0, (size_t) p->n_rays, stream));
     HIP_TRY(hipMemsetAsync(&p->ctl->failure_code, 0, sizeof(unsigned), stream));
     HIP_TRY(hipMemsetAsync(&p->ctl->n_failed, 0, sizeof(unsigned), stream));
-    HIP_TRY(hipMemsetAsync(&p->ctl->next_tile_b, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(p->ctl->next_tile_f, 0, sizeof(p->ctl->next_tile_f), stream));
     p->P.bad  = p->bad_dev;
     p->P.safe = 1;
     int rc    = launch_freq_any(p, stream);
@@ -449,7 +453,7 @@ static int plan_repeat_checked(rt_hip_plan *p)
         if (!p->P.exclusive)
             HIP_TRY(hipMemsetAsync(p->last_image, 0, p->n_image * sizeof(double), stream));
         HIP_TRY(hipMemsetAsync(p->last_iang, 0, p->n_iang * sizeof(double), stream));
-        HIP_TRY(hipMemsetAsync(&p->ctl->next_tile_b, 0, sizeof(unsigned), stream));
+        HIP_TRY(hipMemsetAsync(p->ctl->next_tile_f, 0, sizeof(p->ctl->next_tile_f), stream));
         p->P.safe = 2;
         rc        = launch_freq_any(p, stream);
     }
@@ -636,6 +640,7 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
     }
     for (hipEvent_t e : p->ring) // (with a ring, ev0 / evm / ev1 alias one of its slots)
         (void) hipEventDestroy(e);
+
     pool_free(p->device, p->tan_dev);
     pool_free(p->device, p->rec);
     (void) hipFree(p->path_dev);
