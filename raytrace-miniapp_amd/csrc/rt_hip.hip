@@ -1736,6 +1736,21 @@ extern "C" __global__ void __launch_bounds__(256) rt_interleave_kernel(const dou
 }
 } // namespace rt
 
+namespace rt {
+// loopback rehearsal of the sum-reduce (rt_hip_multi_image_loop): out = sum over parts of recv[part][.]
+extern "C" __global__ void __launch_bounds__(256) rt_sum_parts_kernel(const double *recv, unsigned long long stride, int ndev,
+                                                                     unsigned long long n, double *out)
+{
+    const unsigned long long step = (unsigned long long) gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) {
+        double v = 0.0;
+        for (int r = 0; r < ndev; r++)
+            v += recv[(unsigned long long) r * stride + t];
+        out[t] = v;
+    }
+}
+} // namespace rt
+
 int rt_hip_multi_last_mode(void) { return g_multi_mode; }
 
 int rt_hip_host_libm_mode(int device) { return tan_mode(device); }
@@ -1768,17 +1783,26 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
     }
     if (ndev <= 0 || ndev > have)
         ndev = have;
+    // RT_HIP_MULTI_LOOPBACK=n: rehearsal of an n-device run on ONE device (tests): n workers, n plans, the
+    // same partition, buffers and assembly kernels, all on device 0, with the RCCL collective replaced by
+    // device-to-device copies into the same receive layout.  Exercises everything of the N > 1 path except
+    // the RCCL calls themselves.
+    const int loopback = (int) env_unsigned("RT_HIP_MULTI_LOOPBACK", 0, 1, 16);
+    if (loopback > 0)
+        ndev = loopback;
+    auto dev_of = [&](int d) { return loopback > 0 ? 0 : d; };
     const auto t_begin = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> serial(g_multi_mutex);
-    {
+    RcclApi *R = nullptr;
+    if (loopback == 0) {
         std::string err;
         const int rc = multi_comms(ndev, err);
         if (rc != RT_OK) {
             g_last_error = "rt_hip_multi_image_loop: " + err;
             return rc;
         }
+        R = rccl_api();
     }
-    RcclApi *R = rccl_api();
 
     // ---- how to partition ----------------------------------------------------------------------
     GridGuess G;
@@ -1834,8 +1858,9 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
             return e == hipSuccess;
         };
         // -- plan on this device (the device is bound here, inside the worker)
-        if (hip_ok(hipSetDevice(d), "hipSetDevice")) {
-            q = lease_queue(d);
+        const int pd = dev_of(d); // the physical device of this worker
+        if (hip_ok(hipSetDevice(pd), "hipSetDevice")) {
+            q = lease_queue(pd);
             if (!q)
                 fail(RT_ERR_HIP, "no queue");
         }
@@ -1853,7 +1878,7 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                     bd.nx = 1;
                     bd.x  = xd.data();
                 }
-                rc = rt_hip_plan_create(&p, d, N, &bd, gain, seed, method, scale);
+                rc = rt_hip_plan_create(&p, pd, N, &bd, gain, seed, method, scale);
                 if (rc == RT_OK) {
                     const int cols      = tile_cols(nx, d, ndev);
                     const int64_t count = (int64_t) cols * ny * beam->na * beam->nb;
@@ -1861,7 +1886,7 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                                                   beam->nb, 0, 1, count);
                 }
             } else {
-                rc = rt_hip_plan_create(&p, d, N, beam, gain, seed, method, scale);
+                rc = rt_hip_plan_create(&p, pd, N, beam, gain, seed, method, scale);
                 // contiguous ray chunks, as RayTraceImageThreadLoop splits them (RayTraceImage.cpp:107)
                 const size_t chunk = n_rays / (size_t) ndev + 1;
                 const size_t begin = std::min((size_t) d * chunk, n_rays);
@@ -1874,9 +1899,9 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                 fail(rc, rt_hip_last_error());
         }
         if (w.rc == RT_OK) {
-            hip_ok(pool_alloc(d, (void **) &buf, stride * sizeof(double)), "device buffer");
+            hip_ok(pool_alloc(pd, (void **) &buf, stride * sizeof(double)), "device buffer");
             if (w.rc == RT_OK && d == 0) {
-                if (tiles)
+                if (tiles || loopback > 0)
                     hip_ok(pool_alloc(0, (void **) &recv0, (size_t) ndev * stride * sizeof(double)), "gather buffer");
                 hip_ok(pool_alloc(0, (void **) &out0, (n_img + n_ang) * sizeof(double)), "image buffer");
             }
@@ -1896,7 +1921,32 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                 fail(rc, rt_hip_last_error());
         }
         // -- the one collective of the image, on the queue the kernels ran on
-        if (meet.arrive(w.rc == RT_OK)) {
+        if (loopback > 0) {
+            // rehearsal: every worker copies its part into the receive layout, worker 0 assembles
+            const bool all_ok = meet.arrive(w.rc == RT_OK);
+            if (all_ok) {
+                hip_ok(hipMemcpyAsync(recv0 + (size_t) d * stride, buf, stride * sizeof(double), hipMemcpyDeviceToDevice, q),
+                       "loopback copy");
+                hip_ok(hipStreamSynchronize(q), "hipStreamSynchronize");
+            }
+            if (meet.arrive(w.rc == RT_OK) && d == 0) {
+                const unsigned long long n_out = (unsigned long long) (tiles ? n_img : stride);
+                unsigned blocks = (unsigned) std::min<unsigned long long>((n_out + 255) / 256, 256ull * 64ull);
+                blocks          = blocks ? blocks : 1;
+                if (tiles)
+                    hipLaunchKernelGGL(rt::rt_interleave_kernel, dim3(blocks), dim3(256), 0, q, recv0, (unsigned long long) stride,
+                                       ndev, nx, ny, K, (unsigned long long) n_tile_max, (int) n_ang, out0, out0 + n_img);
+                else
+                    hipLaunchKernelGGL(rt::rt_sum_parts_kernel, dim3(blocks), dim3(256), 0, q, recv0, (unsigned long long) stride,
+                                       ndev, (unsigned long long) stride, out0);
+                hip_ok(hipGetLastError(), "assembly kernel");
+                hip_ok(hipStreamSynchronize(q), "hipStreamSynchronize");
+                if (w.rc == RT_OK) {
+                    hip_ok(hipMemcpy(image, out0, n_img * sizeof(double), hipMemcpyDeviceToHost), "download image");
+                    hip_ok(hipMemcpy(I_ang, out0 + n_img, n_ang * sizeof(double), hipMemcpyDeviceToHost), "download I_ang");
+                }
+            }
+        } else if (meet.arrive(w.rc == RT_OK)) {
             ncclResult_t r = ncclSuccess;
             if (tiles) {
                 r = R->GroupStart();
@@ -1929,15 +1979,15 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
         // every worker is past the collective before any buffer of it goes back to the pool
         meet.arrive(true);
         rt_hip_plan_destroy(p);
-        (void) hipSetDevice(d);
+        (void) hipSetDevice(pd);
         if (q)
             (void) hipStreamSynchronize(q);
-        pool_free(d, buf);
+        pool_free(pd, buf);
         if (d == 0) {
             pool_free(0, recv0);
             pool_free(0, out0);
         }
-        release_queue(d, q);
+        release_queue(pd, q);
     };
     std::vector<std::thread> th;
     for (int d = 0; d < ndev; d++)

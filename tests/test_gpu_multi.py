@@ -131,3 +131,34 @@ def test_host_libm_probe_and_host_tangent_fallback(hip, oracle, ase_small):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_HIP_TAN_ON_HOST="1"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 5, 8])
+def test_multi_loop_partition_and_assembly_for_several_devices(hip, oracle, ase_small, seed_small, monkeypatch, ndev):
+    """The N > 1 logic of rt_hip_multi_image_loop -- pixel-column tiles (equal and unequal widths), tile
+    buffers, the interleave kernel and the I_ang sum; ray chunks and the summed images -- rehearsed on the one
+    GPU of this box: RT_HIP_MULTI_LOOPBACK runs n workers with n plans on device 0 and replaces only the RCCL
+    collective by device-to-device copies into the same receive layout."""
+    monkeypatch.setenv("RT_HIP_MULTI_LOOPBACK", str(ndev))
+    p = rt.scale_problem(ase_small, 0.3)                       # nx = 44: unequal tiles for 3, 5, 8 devices
+    assert p.beam.nx % 3 != 0
+    one = hip.image_loop(p)
+    out = hip.multi_image_loop(p)
+    assert out["mode"] == 1 and out["failure_code"] == 0
+    assert out["stats"]["n_rays"] == p.n_rays_total and out["stats"]["cell_steps"] == one["stats"]["cell_steps"]
+    ref = oracle.image_loop(p, n_threads=8)
+    assert rel_l2(out["image"], ref["image"]) < 1e-6 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-6
+    assert rel_l2(out["image"], one["image"]) < 1e-12 and rel_l2(out["I_ang"], one["I_ang"]) < 1e-12
+    # seeded: ray chunks of the seed-beam grid, full images summed
+    q = rt.scale_problem(seed_small, 0.02)
+    one = hip.image_loop(q)
+    out = hip.multi_image_loop(q)
+    assert out["mode"] == 2
+    assert out["stats"]["n_rays"] == q.n_rays_total and out["stats"]["cell_steps"] == one["stats"]["cell_steps"]
+    assert rel_l2(out["image"], one["image"]) < 1e-12 and rel_l2(out["I_ang"], one["I_ang"]) < 1e-12
+    # an arbitrary list: chunks of the list itself
+    rays = ase_small.build_rays()[7:-3:5].copy()
+    ref = oracle.image_loop(ase_small, rays, n_threads=8)
+    out = hip.multi_image_loop(ase_small, rays)
+    assert out["mode"] == 2 and out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    assert rel_l2(out["image"], ref["image"]) < 1e-6 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-6
