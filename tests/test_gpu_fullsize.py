@@ -137,6 +137,26 @@ def copy_beam_window(p, i0, j0, T):
     return q
 
 
+def test_bench_two_rank_seeded_rehearsal(hip):
+    """The seeded form of the N-rank bench (source columns sharded, ONE sum-reduce of image | I_ang): 124.8 M
+    rays split over two ranks that share this box's GPU, collective staged through gloo."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "seed_medium", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["config"]["rays_total"] == 124848000
+    assert line["config"]["parallelism"] == "source-columns x2"
+    assert "reduce" in line["multi_gpu"]["collective"]
+
+
 def test_bench_two_rank_launch_rehearsal(hip):
     """`python bench.py --gpus 2` must start its ranks itself (the driver launches it that way too).  This
     box has one GPU, so the rehearsal puts both ranks on device 0 and stages the collective through gloo;
