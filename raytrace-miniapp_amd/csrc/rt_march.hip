@@ -442,7 +442,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 st        = ST_CELL;
             }
         }
-        if (__ballot(st != ST_IDLE) == 0ull) {
+        // (at this point every lane is idle, waits for [A], or is in [B] / [C]: the three lane masks the loop
+        // head needs follow from two ballots)
+        const unsigned long long idle2 = __ballot(st == ST_IDLE);
+        if (idle2 == ~0ull) {
             if (!more)
                 break;
         } else {
@@ -459,9 +462,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // P.park -- in the tail of a launch, when a wave is down to a few rays, a fixed threshold would make
         // each of them wait for all the others: 1024 rays took 0.34 ms with it, as long as 400 000)
         const unsigned long long want_a = __ballot(st == ST_CELL);
-        const int n_live  = WAVE - n_idle;
-        const int park_at = (n_live + 4) / 5 < (int) P.park ? (n_live + 4) / 5 : (int) P.park;
-        const bool do_a = (int) __popcll(want_a) >= park_at || __ballot((st == ST_XSETUP) | (st == ST_STEP)) == 0ull;
+        const int n_live  = WAVE - (int) __popcll(idle2);
+        const int fifth   = (n_live * 13 + 63) >> 6; // ~ n_live / 5, at least 1 for a live lane
+        const int park_at = fifth < (int) P.park ? fifth : (int) P.park;
+        const bool do_a = (int) __popcll(want_a) >= park_at || (~(idle2 | want_a)) == 0ull;
         if (do_a && st == ST_CELL) {
             bool in_seg        = !escaped & (z < 0.995f * z_stop);
             if (!in_seg) {
