@@ -289,6 +289,9 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 sub-record of the default N = 1 run")
     ap.add_argument("--no-extras", action="store_true", help="only the timed loop (profiling runs)")
+    ap.add_argument("--no-assemble", action="store_true",
+                    help="N > 1: leave the tiles on their GPUs (config 5: gathering the 68.7 GB image takes longer than "
+                         "tracing it, SURVEY.md 7.3-6); the collective is then reported as absent")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -343,7 +346,7 @@ def main() -> int:
 
     def step():
         plan.run(stream, image.data_ptr(), iang.data_ptr())
-        if world > 1:
+        if world > 1 and not args.no_assemble:
             asm.assemble()
 
     for _ in range(args.warmup):
@@ -380,7 +383,7 @@ def main() -> int:
     # The weak-scaling form of the same workload (every rank the whole single-GPU workload) is measured after
     # the timed run, same protocol, and reported beside it -- extra information, never `value`.
     weak = None
-    if world > 1 and scaling == "strong" and not args.no_extras:
+    if world > 1 and scaling == "strong" and not args.no_extras and args.workload == "standin":
         wfull, _ = build_workload(rt, problem_mod, args.workload, world, "weak")
         wmine = multigpu.shard(wfull, rank, world)
         wplan = backend.Plan(wmine, device=local)
@@ -471,7 +474,7 @@ def main() -> int:
             line["multi_gpu"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
                                  "kernel_ms_max_over_ranks": kernel_ms_max,
                                  "assembly_ms": max(0.0, ms_step - kernel_ms_max),
-                                 "collective": asm.describe()}
+                                 "collective": "none (--no-assemble: tiles stay on their GPUs)" if args.no_assemble else asm.describe()}
             if weak is not None:
                 line["multi_gpu"]["weak_scaling"] = weak
         if world == 1 and not args.no_extras:
