@@ -185,6 +185,54 @@ struct DevParams {
     unsigned char *bad; // [n_rays], only in the repeat
 };
 
+// ---- argument block of the frequency kernel (rt_freq.hip) ------------------------------------
+// The kernel argument is FreqKArg = { hot, cold }.  `hot` is what the frequency loop reads: the
+// compiler loads it once and keeps it in SGPRs.  `cold` is what the per-ray preamble of a tile
+// reads (beam grids, seed tables, ray grids, probe outputs): the kernel takes its address inside
+// the kernarg segment and reads the fields it needs where it needs them (scalar loads), so none of
+// them is live across the frequency loop.  (With one ~600-byte by-value block every field was
+// hoisted to the kernel entry: 207 SGPR spills and a dependent global load per frequency batch.)
+struct FreqCold {
+    DevBeam beam;
+    DevSeed seed;
+    DevRays rays;
+    DevProbe probe;
+};
+enum : unsigned {
+    FQ_EXCLUSIVE  = 1u,   // DevParams::exclusive
+    FQ_SAFE_CHECK = 2u,   // DevParams::safe == 1: integrate without depositing, mark failing rays
+    FQ_SAFE_SKIP  = 4u,   // DevParams::safe == 2: deposit all rays but the marked ones
+    FQ_EXACT_EMIS = 8u,   // DevParams::exact_emis
+    FQ_HAS_SEED   = 16u,
+    FQ_PROBE      = 32u,
+    FQ_GV_NAN     = 64u,  // some lineshape value is a NaN (found by the host scan): test per frequency
+    FQ_IANG_LDS   = 128u, // the I_ang histogram of a work-group lives in LDS
+    FQ_NEED_EXIT  = 256u  // the exit angles are needed (forward method, seed, or probe)
+};
+struct FreqHot {
+    const float *gv0, *gv1; // SF == 6 (N = 3): lineshape tables of lengths 1 and 2, rows of Kp floats
+    const DevGain *gain;    // any N: [N] lineshape pointers, entry 0 unused
+    const unsigned char *rec;
+    double *image;
+    double *iang;
+    DevCtl *ctl;
+    const double *dv2;      // [Kp] 2 * beam.dv (RayTraceImageCPU.cpp:66), zero padded
+    const double *seed_fk;  // [Kp] seed.f[4], zero padded; NULL without a seed
+    unsigned char *bad;     // [n_rays] failing-ray marks of the checking repeat, else NULL
+    double scale;
+    float gs_cap;
+    int K, Kp, L, method;
+    unsigned rec_stride, n_rays;
+    unsigned tile_begin, tile_end, freq_id;
+    unsigned flags; // FQ_*
+    int nslot;      // rows of the per-wave LDS row cache
+    int nx, ny, n_ang;
+};
+struct FreqKArg {
+    FreqHot hot;
+    FreqCold cold;
+};
+
 // packing of RecMeta::flags_steps
 constexpr unsigned REC_FLAG_MASK = 0xfu, REC_NDONE_SHIFT = 4, REC_NDONE_MASK = 0xffu, REC_STEPS_SHIFT = 12;
 

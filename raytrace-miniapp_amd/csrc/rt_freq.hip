@@ -26,7 +26,7 @@ namespace rt {
 #define RT_FREQ_WAVES_SEED 4 // the gain-only instance keeps far less per-lane state
 #endif
 #ifndef RT_FREQ_WAVES
-#define RT_FREQ_WAVES 3 // waves per SIMD of the emission instance (<= 168 VGPRs; at 4, i.e. 128, it spills)
+#define RT_FREQ_WAVES 4 // waves per SIMD of the emission instance (127 VGPRs, no scratch; 168 at 3 before the argument block was split)
 #endif
 
 constexpr int VEC = 4; // frequencies per lane and pass; rows are padded to a multiple (DevParams::Kp)
@@ -205,97 +205,119 @@ constexpr int XS_ROW          = 17; // exclusive mode: staging row of 16 frequen
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
 
+// constant-address-space views: loads through them are scalar (s_load), whatever else the kernel stores
+#define RT_CONST_AS __attribute__((address_space(4)))
+typedef const RT_CONST_AS FreqCold *ColdPtr;
+typedef const RT_CONST_AS double *ConstF64;
+// a copy of one member struct of the cold block (dword loads through the constant address space)
+template <typename T> __device__ __forceinline__ T load_cold(const RT_CONST_AS T *src)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword copy");
+    T r;
+    unsigned *d                   = reinterpret_cast<unsigned *>(&r);
+    const RT_CONST_AS unsigned *q = reinterpret_cast<const RT_CONST_AS unsigned *>(src);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++)
+        d[i] = q[i];
+    return r;
+}
+
 template <int SF, bool EMIS>
-__device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, const double *tab, double *xpose,
-                                          double *cache, const int nslot, const unsigned tile, const int lane)
+__device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflags, ColdPtr C, double *lds_iang, const double *tab,
+                                          double *xpose, double *cache, const unsigned tile, const int lane)
 {
     double *win = xpose + 4 * XP_ROW; // [MAXQ][64] totals of the current window of 64 frequencies
-    const int S           = SF ? SF : P.L * RT_N_SUB;
-    const int K           = P.K;
-    const int Kp          = P.Kp; // row stride of the lineshape tables and of the row cache
-    const unsigned n_rays = (unsigned) P.rays.count;
+    const int S           = SF ? SF : H.L * RT_N_SUB;
+    const int K           = H.K;
+    const int Kp          = H.Kp; // row stride of the lineshape tables and of the row cache
+    const int nslot       = H.nslot;
+    const unsigned n_rays = H.n_rays;
     const unsigned ridx   = tile * WAVE + (unsigned) lane;
     const bool have       = ridx < n_rays;
-    const unsigned char *rec = P.rec + (size_t) (have ? ridx : 0) * P.rec_stride;
+    const bool backward   = H.method == 1;
+    const unsigned char *rec = H.rec + (size_t) (have ? ridx : 0) * H.rec_stride;
     constexpr bool use_emis = EMIS; // Helper.h:402, fixed per kernel instance (see launch_freq)
+    const bool safe_check = (hflags & FQ_SAFE_CHECK) != 0, safe_skip = (hflags & FQ_SAFE_SKIP) != 0;
+    const bool probe_on   = (hflags & FQ_PROBE) != 0;
 
     // ---- per-ray preamble: exit ray, seed factor, deposit cells ------------------
+    // (everything read through C is loaded here and dead before the frequency loop)
     unsigned fl = 0, steps = 0;
     rt_ray ray  = { 0, 0, 0, 0 };
     RecMeta m   = { 0, 0, 0, 0, 1, 0 };
+    const DevRays R = load_cold(&C->rays);
     if (have) {
         m     = *reinterpret_cast<const RecMeta *>(rec + 12 * (size_t) S);
         fl    = m.flags_steps & REC_FLAG_MASK;
         steps = m.flags_steps >> REC_STEPS_SHIFT;
         float ta, tb;
-        load_ray(P.rays, ridx, ray, ta, tb, false);
+        load_ray(R, ridx, ray, ta, tb, false);
     }
     bool err1   = have && (double) (m.sz * m.sz) < 0.01; // Helper.h:515
     rt_ray out  = ray;
     double f0   = 0.0;
     int pix = -1, ang = -1;
     if (have && !err1) {
-        const bool need_exit = P.method != 1 || P.has_seed || P.probe_on;
         rt_ray r2 = { m.px, m.py, 0.0f, 0.0f };
-        if (need_exit) {
+        if (hflags & FQ_NEED_EXIT) {
             // Helper.h:518-521: atanf(s.x / s.z) * 1e3f
             r2.a = atanf_flt32_kernel(m.sx / m.sz) * 1e3f;
             r2.b = atanf_flt32_kernel(m.sy / m.sz) * 1e3f;
         }
-        if (P.has_seed && !(fl & F_ESCAPED)) { // Helper.h:523-533
-            if (P.method == 1) {
-                f0 = seed_factor(P.seed, (double) m.px, (double) m.py, (double) r2.a, (double) r2.b);
-            } else if (P.rays.sf) {
+        if ((hflags & FQ_HAS_SEED) && !(fl & F_ESCAPED)) { // Helper.h:523-533
+            if (backward || !R.sf) {
+                const DevSeed SD = load_cold(&C->seed);
+                f0 = backward ? seed_factor(SD, (double) m.px, (double) m.py, (double) r2.a, (double) r2.b)
+                              : seed_factor(SD, (double) ray.x, (double) ray.y, (double) ray.a, (double) ray.b);
+            } else {
                 // the launch ray is a grid point: product of the tabulated factors, in seed_factor's order
                 unsigned gi, gj, gk, gm;
-                grid_index(P.rays, ridx, gi, gj, gk, gm);
-                const unsigned oj = (unsigned) P.rays.ngx, ok = oj + (unsigned) P.rays.ngy, om = ok + (unsigned) P.rays.nga;
-                if (P.rays.sin[gi] & P.rays.sin[oj + gj] & P.rays.sin[ok + gk] & P.rays.sin[om + gm]) {
-                    f0 = P.seed.f0 * P.rays.sf[gi] * P.rays.sf[oj + gj] * P.rays.sf[ok + gk] * P.rays.sf[om + gm];
+                grid_index(R, ridx, gi, gj, gk, gm);
+                const unsigned oj = (unsigned) R.ngx, ok = oj + (unsigned) R.ngy, om = ok + (unsigned) R.nga;
+                if (R.sin[gi] & R.sin[oj + gj] & R.sin[ok + gk] & R.sin[om + gm]) {
+                    f0 = C->seed.f0 * R.sf[gi] * R.sf[oj + gj] * R.sf[ok + gk] * R.sf[om + gm];
                     f0 = f0 < 0.0 ? 0.0 : f0;
                 }
-            } else {
-                f0 = seed_factor(P.seed, (double) ray.x, (double) ray.y, (double) ray.a, (double) ray.b);
             }
         }
-        if (P.method != 1) { // RayTraceImageCPU.cpp:37-49
+        if (!backward) { // RayTraceImageCPU.cpp:37-49
             out   = r2;
             out.a = -out.a;
             out.b = -out.b;
-            if ((double) out.y < 0.0 && P.beam.y[0] >= 0.0)
+            if ((double) out.y < 0.0 && C->beam.y[0] >= 0.0)
                 out.y = -out.y;
         }
-        if (P.probe_on)
-            P.probe.ray2[ridx] = r2;
-        const int i1 = deposit_index_fast(P.beam.nx, P.beam.x, P.beam.dx, P.beam.inv_dx, (double) out.x);
-        const int i2 = deposit_index_fast(P.beam.ny, P.beam.y, P.beam.dy, P.beam.inv_dy, (double) out.y);
-        const int i3 = deposit_index_fast(P.beam.na, P.beam.a, P.beam.da, P.beam.inv_da, (double) out.a);
-        const int i4 = deposit_index_fast(P.beam.nb, P.beam.b, P.beam.db, P.beam.inv_db, (double) out.b);
+        if (probe_on)
+            C->probe.ray2[ridx] = r2;
+        const int i1 = deposit_index_fast(C->beam.nx, C->beam.x, C->beam.dx, C->beam.inv_dx, (double) out.x);
+        const int i2 = deposit_index_fast(C->beam.ny, C->beam.y, C->beam.dy, C->beam.inv_dy, (double) out.y);
+        const int i3 = deposit_index_fast(C->beam.na, C->beam.a, C->beam.da, C->beam.inv_da, (double) out.a);
+        const int i4 = deposit_index_fast(C->beam.nb, C->beam.b, C->beam.db, C->beam.inv_db, (double) out.b);
         if (i1 >= 0 && i2 >= 0)
-            pix = i1 + i2 * P.beam.nx;
+            pix = i1 + i2 * H.nx;
         if (i3 >= 0 && i4 >= 0)
-            ang = i3 + i4 * P.beam.na;
+            ang = i3 + i4 * C->beam.na;
     }
-    if (have && P.probe_on) {
-        P.probe.flags[ridx] = fl | (err1 ? F_ERR1 : 0u);
-        P.probe.steps[ridx] = steps;
+    if (have && probe_on) {
+        C->probe.flags[ridx] = fl | (err1 ? F_ERR1 : 0u);
+        C->probe.steps[ridx] = steps;
     }
-    if (err1 && P.safe != 2) { // error -1: the ray is reported and deposits nothing
-        atomicOr(&P.ctl->failure_code, 1u << 1);
-        unsigned slot_f = atomicAdd(&P.ctl->n_failed, 1u);
+    if (err1 && !safe_skip) { // error -1: the ray is reported and deposits nothing
+        atomicOr(&H.ctl->failure_code, 1u << 1);
+        unsigned slot_f = atomicAdd(&H.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
-            P.ctl->failed[slot_f] = ray;
+            H.ctl->failed[slot_f] = ray;
     }
-    const bool live = have && !err1 && !(fl & F_SKIP) && !(P.safe == 2 && P.bad[ridx]);
+    const bool live = have && !err1 && !(fl & F_SKIP) && !(safe_skip && H.bad[ridx]);
     // exclusive mode: this ray is the only contributor of pixel own_pix and must write its
     // whole row (zeros if it contributes nothing); a ray that deposits elsewhere (never the
     // case for a consistent grid) keeps the atomic path for the foreign pixel.
+    const bool excl_all = (hflags & FQ_EXCLUSIVE) != 0;
     int own_pix = -1;
-    if (P.exclusive && have) {
-        const unsigned j = ridx % (unsigned) P.beam.ny, i = ridx / (unsigned) P.beam.ny;
-        own_pix          = (int) (i + j * (unsigned) P.beam.nx);
+    if (excl_all && have) {
+        const unsigned j = ridx % (unsigned) H.ny, i = ridx / (unsigned) H.ny;
+        own_pix          = (int) (i + j * (unsigned) H.nx);
     }
-    const bool excl_all = P.exclusive != 0;
     if (__ballot(live) == 0ull && !excl_all)
         return;
     if (!live) {
@@ -337,22 +359,25 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     }
 
     // ---- the march record of this lane's ray ---------------------------------------
+    // off[s]: byte offset of the lineshape row of sub-segment s inside its length's table (32 bits:
+    // rt_hip_plan_create refuses tables of 4 GiB), so that a row load is SGPR base + VGPR offset
     float gs[SF ? SF : 1];
     double rs[SF ? SF : 1]; // es/gs, the source function of the sub-segment (see ase_step)
-    int cs[SF ? SF : 1];
+    unsigned off[SF ? SF : 1];
+    const bool exact_emis = (hflags & FQ_EXACT_EMIS) != 0;
     bool irregular = false;
     if (SF) {
 #pragma unroll
         for (int s = 0; s < SF; s++) {
-            const RecSlot sl = rec_slot(rec, s, SF, m.flags_steps, P.method == 1);
+            const RecSlot sl = rec_slot(rec, s, SF, m.flags_steps, backward);
             gs[s]            = sl.g;
             const float e1   = sl.e;
-            cs[s]            = sl.c;
+            off[s]           = (unsigned) sl.c * (unsigned) Kp * 4u;
             // regular: the source-function form (ase_step) takes this sub-segment; not when the gain
             // sum is tiny or NaN, and never in the exact mode (rt_hip_plan_set_exact_emission), which
             // runs the CPU's own formula with its per-frequency division throughout
             // (|gs| <= gs_cap keeps |gs * gv| <= 708 for every lineshape value; NaN fails both tests)
-            const bool regular = fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= P.gs_cap && !P.exact_emis;
+            const bool regular = fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= H.gs_cap && !exact_emis;
             rs[s]              = regular ? div_fast((double) e1, (double) gs[s]) : 0.0;
             // (a sub-segment with both sums zero is the identity either way: x = 0, e^x - 1 = 0)
             irregular = irregular || (!regular && (gs[s] != 0.0f || e1 != 0.0f));
@@ -361,41 +386,49 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
     // no such sub-segment in the whole tile (the rule): the six updates of a frequency batch run
     // as one straight-line block, so the table reads of one overlap the arithmetic of another
     const bool all_regular = __ballot(irregular) == 0ull;
+    // a NaN among the lineshape values (the CPU's 0 * NaN) is tested per frequency only when the host
+    // scan of the tables found one
+    const bool gv_nan = (hflags & FQ_GV_NAN) != 0;
 
     double angsum = 0.0; // RayTraceImageCPU.cpp:63-68, sequential in k like the CPU
     double iv_min = 0.0; // min over k of Iv, NaNs ignored: negative <=> error -2 (Helper.h:582-594)
-    double *img_row = P.image + (size_t) (pix >= 0 ? pix : 0) * (size_t) K;
+    double *img_row = H.image + (size_t) (pix >= 0 ? pix : 0) * (size_t) K;
+    const ConstF64 dv2 = (ConstF64) (unsigned long long) H.dv2;      // wave-uniform reads: scalar loads
+    const ConstF64 sfk = (ConstF64) (unsigned long long) H.seed_fk;
+
+    // row of sub-segment s, frequencies kb .. kb+3 (SF: the tables of lengths 1 and 2 are kernel arguments)
+    auto load_rows = [&](FVec (&w)[SF ? SF : 1], const int kb) {
+#pragma unroll
+        for (int s = 0; s < (SF ? SF : 1); s++) {
+            const float *base = (s < RT_N_SUB ? H.gv0 : H.gv1) + kb;
+            // (opaque here, so that the zero-extension of the offset stays beside the load and the
+            // instruction selector finds the SGPR-base + 32-bit-VGPR-offset form)
+            unsigned o = off[s];
+            asm volatile("" : "+v"(o));
+#ifdef RT_ABL_NOLOAD
+            o &= 15u;
+#endif
+            w[s] = *reinterpret_cast<const FVec *>(reinterpret_cast<const char *>(base) + o);
+        }
+    };
 
     // The frequency loop, instantiated once per deposit mode (exclusive / few runs / row
     // cache / segmented scan) so that each instance keeps only its own deposit state in
     // registers: `deposit(kb, v)` consumes the lane's values of frequencies kb .. kb+VEC-1.
     auto frequency_loop = [&](auto deposit) {
+        // (Requesting the rows of batch kb + 1 early was measured and dropped: a second set of row registers costs
+        // the fourth wave per SIMD, 1.34 against 1.30 ms; a request into the same registers right after batch kb
+        // has consumed its own, so that the rows travel during the deposit, 1.31 against 1.30 ms and 1.65 against
+        // 1.60 ms seeded -- with four waves per SIMD the latency is covered by the other waves.)
         for (int kb = 0; kb < K; kb += VEC) {
             double Iv[VEC];
             if (use_emis) {
-                bool wnan[VEC]; // a NaN anywhere in this frequency's lineshape values (0 * NaN on the CPU)
 #pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    Iv[j]   = 0.0;
-                    wnan[j] = false;
-                }
+                for (int j = 0; j < VEC; j++)
+                    Iv[j] = 0.0;
                 if (SF) {
                     FVec w[SF ? SF : 1];
-#pragma unroll
-                    for (int s = 0; s < SF; s++) {
-#ifdef RT_ABL_NOLOAD
-                        const float *row = P.gain[s / RT_N_SUB + 1].gv + kb;
-#else
-                        const float *row = P.gain[s / RT_N_SUB + 1].gv + (size_t) cs[s] * (size_t) Kp + kb;
-#endif
-                        w[s] = *reinterpret_cast<const FVec *>(row);
-                    }
-#pragma unroll
-                    for (int s = 0; s < SF; s++) {
-#pragma unroll
-                        for (int j = 0; j < VEC; j++)
-                            wnan[j] = wnan[j] || w[s].v[j] != w[s].v[j];
-                    }
+                    load_rows(w, kb);
                     if (all_regular) {
 #pragma unroll
                         for (int s = 0; s < SF; s++)
@@ -403,10 +436,10 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     } else
 #pragma unroll
                     for (int s = 0; s < SF; s++) {
-                        if (fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= P.gs_cap && !P.exact_emis) {
+                        if (fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= H.gs_cap && !exact_emis) {
                             ase_step(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
-                            const float e1 = rec_slot(rec, s, SF, m.flags_steps, P.method == 1).e;
+                            const float e1 = rec_slot(rec, s, SF, m.flags_steps, backward).e;
                             if (gs[s] != 0.0f || e1 != 0.0f) { // else the update is the identity
 #pragma unroll
                                 for (int j = 0; j < VEC; j++)
@@ -414,17 +447,31 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                             }
                         }
                     }
+                    if (gv_nan) {
+#pragma unroll
+                        for (int j = 0; j < VEC; j++) {
+                            bool wn = false;
+#pragma unroll
+                            for (int s = 0; s < SF; s++)
+                                wn = wn || w[s].v[j] != w[s].v[j];
+                            Iv[j] = wn ? __builtin_nan("") : Iv[j];
+                        }
+                    }
                 } else {
+                    bool wnan[VEC]; // a NaN anywhere in this frequency's lineshape values (0 * NaN on the CPU)
+#pragma unroll
+                    for (int j = 0; j < VEC; j++)
+                        wnan[j] = false;
                     for (int s = 0; s < S; s++) {
-                        const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, P.method == 1);
+                        const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, backward);
                         const float g1 = sl.g, e1 = sl.e;
                         const int c1   = sl.c;
-                        const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
+                        const float *row  = H.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
                         const FVec w = *reinterpret_cast<const FVec *>(row);
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
                             wnan[j] = wnan[j] || w.v[j] != w.v[j];
-                        if (fabsf(g1) >= RT_RS_MIN && fabsf(g1) <= P.gs_cap && !P.exact_emis) {
+                        if (fabsf(g1) >= RT_RS_MIN && fabsf(g1) <= H.gs_cap && !exact_emis) {
                             const double r1 = div_fast((double) e1, (double) g1);
                             ase_step(Iv, g1, r1, w.v, tab);
                         } else if (g1 != 0.0f || e1 != 0.0f) {
@@ -433,29 +480,34 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                                 Iv[j] = ase_update(Iv[j], g1, e1, w.v[j], tab);
                         }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < VEC; j++)
-                    Iv[j] = wnan[j] ? __builtin_nan("") : Iv[j];
+                    for (int j = 0; j < VEC; j++)
+                        Iv[j] = wnan[j] ? __builtin_nan("") : Iv[j];
+                }
             } else {
                 // gain only, Helper.h:569-580: f64 products summed in sub-segment order
                 double gl[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; j++)
                     gl[j] = 0.0;
+                if (SF) {
+                    FVec w[SF ? SF : 1];
+                    load_rows(w, kb);
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const float g1    = SF ? gs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).g;
-                    const int c1      = SF ? cs[SF ? s : 0] : rec_slot(rec, s, S, m.flags_steps, P.method == 1).c;
-#ifdef RT_ABL_NOLOAD
-                    const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) (c1 & 1) * (size_t) Kp + kb;
-#else
-                    const float *row  = P.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
-#endif
-                    const FVec w = *reinterpret_cast<const FVec *>(row);
+                    for (int s = 0; s < SF; s++) {
 #pragma unroll
-                    for (int j = 0; j < VEC; j++)
-                        gl[j] += (double) g1 * (double) w.v[j];
+                        for (int j = 0; j < VEC; j++)
+                            gl[j] += (double) gs[s] * (double) w[s].v[j];
+                    }
+                } else {
+                    for (int s = 0; s < S; s++) {
+                        const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, backward);
+                        const float *row = H.gain[s / RT_N_SUB + 1].gv + (size_t) sl.c * (size_t) Kp + kb;
+                        const FVec w     = *reinterpret_cast<const FVec *>(row);
+#pragma unroll
+                        for (int j = 0; j < VEC; j++)
+                            gl[j] += (double) sl.g * (double) w.v[j];
+                    }
                 }
                 // Iv = f0 f[4][k] exp(gl); for f0 = 0 that is exactly 0 unless exp overflows (0 * inf):
                 // a wave none of whose lanes needs the exponential skips it
@@ -465,7 +517,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     need = need || gl[j] > 700.0 || gl[j] != gl[j];
 #pragma unroll
                 for (int j = 0; j < VEC; j++)
-                    Iv[j] = f0 * P.seed.f[4][kb + j];
+                    Iv[j] = f0 * sfk[kb + j];
                 if (__ballot(need) != 0ull) {
                     double eg[VEC];
                     exp_tab_vec(gl, tab, eg);
@@ -480,11 +532,11 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
                 iv_min = fmin(iv_min, Iv[j]);
-                angsum += (2.0 * P.beam.dv[kb + j]) * Iv[j]; // RayTraceImageCPU.cpp:66
-                Iv[j] = Iv[j] * P.scale;                     // RayTraceImageCPU.cpp:59
+                angsum += dv2[kb + j] * Iv[j]; // RayTraceImageCPU.cpp:66: (2.0 * dv) * Iv
+                Iv[j] = Iv[j] * H.scale;       // RayTraceImageCPU.cpp:59
             }
 #ifndef RT_ABL_NODEPOSIT
-            if (P.safe != 1) // the checking pass of a failing run integrates without depositing
+            if (!safe_check) // the checking pass of a failing run integrates without depositing
                 deposit(kb, Iv);
 #endif
         }
@@ -512,7 +564,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
                     const int row  = 4 * g + (lane >> 4);
                     const int opix = __shfl(own_pix, row, WAVE);
                     if (opix >= 0 && k < K)
-                        P.image[(size_t) opix * (size_t) K + (size_t) k] = cache[row * XS_ROW + (lane & 15)];
+                        H.image[(size_t) opix * (size_t) K + (size_t) k] = cache[row * XS_ROW + (lane & 15)];
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -565,7 +617,7 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
 #pragma unroll
                 for (int q = 0; q < MAXQ; q++) {
                     if (pixq[q] >= 0 && k < K)
-                        unsafeAtomicAdd(&P.image[(size_t) pixq[q] * (size_t) K + (size_t) k], win[q * WAVE + lane]);
+                        unsafeAtomicAdd(&H.image[(size_t) pixq[q] * (size_t) K + (size_t) k], win[q * WAVE + lane]);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -622,42 +674,45 @@ __device__ __forceinline__ void freq_tile(const DevParams &P, double *lds_iang, 
             for (int k = lane; k < K; k += WAVE) {
                 const double v = cache[q * Kp + k];
                 cache[q * Kp + k] = 0.0;
-                unsafeAtomicAdd(&P.image[(size_t) pq * (size_t) K + (size_t) k], v);
+                unsafeAtomicAdd(&H.image[(size_t) pq * (size_t) K + (size_t) k], v);
             }
         }
     }
     // a NaN intensity makes the I_ang sum NaN (Helper.h:590-593: error -3, after the sign test)
     const bool bad_neg = iv_min < 0.0, bad_nan = angsum != angsum;
-    if (live && (bad_neg || bad_nan) && P.safe != 2) {
-        atomicOr(&P.ctl->failure_code, bad_neg ? (1u << 2) : (1u << 3));
-        unsigned slot_f = atomicAdd(&P.ctl->n_failed, 1u);
+    if (live && (bad_neg || bad_nan) && !safe_skip) {
+        atomicOr(&H.ctl->failure_code, bad_neg ? (1u << 2) : (1u << 3));
+        unsigned slot_f = atomicAdd(&H.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
-            P.ctl->failed[slot_f] = ray;
-        if (P.safe == 1)
-            P.bad[ridx] = 1;
+            H.ctl->failed[slot_f] = ray;
+        if (safe_check)
+            H.bad[ridx] = 1;
     }
     // a failing ray adds nothing to I_ang (RayTraceImageCPU.cpp:29-36: `continue` before the deposit)
-    if (ang >= 0 && P.safe != 1 && !(bad_neg || bad_nan)) {
+    if (ang >= 0 && !safe_check && !(bad_neg || bad_nan)) {
         if (lds_iang)
             unsafeAtomicAdd(&lds_iang[ang], angsum);
         else
-            unsafeAtomicAdd(&P.iang[ang], angsum);
+            unsafeAtomicAdd(&H.iang[ang], angsum);
     }
 }
 
 template <int SF, bool EMIS>
-__global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED) rt_freq_kernel(const DevParams P, const int iang_in_lds, const int nslot)
+__global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED) rt_freq_kernel(const FreqKArg A)
 {
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double exp2_tab[EXP_TAB]; // 2^(j/256), j = 0..255
     __shared__ __align__(16) double xpose_wg[4 * FREQ_WAVE_XPOSE];
+    const FreqHot &H      = A.hot;
+    const bool iang_in_lds = (H.flags & FQ_IANG_LDS) != 0;
+    const int nslot       = H.nslot;
     double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
-    const int n_ang  = P.beam.na * P.beam.nb;
+    const int n_ang  = H.n_ang;
     double *cache_wg = reinterpret_cast<double *>(lds_raw) + (iang_in_lds ? n_ang : 0);
     // per wave: the row cache [nslot][Kp], or in exclusive mode the store staging rows [64][XS_ROW]
-    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * (P.exclusive ? (size_t) WAVE * XS_ROW : (size_t) nslot * (size_t) P.Kp);
-    for (int c = (int) threadIdx.x; c < 4 * nslot * P.Kp; c += (int) blockDim.x)
+    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * ((H.flags & FQ_EXCLUSIVE) ? (size_t) WAVE * XS_ROW : (size_t) nslot * (size_t) H.Kp);
+    for (int c = (int) threadIdx.x; c < 4 * nslot * H.Kp; c += (int) blockDim.x)
         cache_wg[c] = 0.0;
     for (int c = (int) threadIdx.x; c < EXP_TAB; c += (int) blockDim.x)
         exp2_tab[c] = exp2((double) c * (1.0 / EXP_TAB));
@@ -670,18 +725,27 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
     for (;;) {
         unsigned tile = 0;
         if (lane == 0)
-            tile = P.tile_begin + atomicAdd(&P.ctl->next_tile_f[P.freq_id], 1u);
+            tile = H.tile_begin + atomicAdd(&H.ctl->next_tile_f[H.freq_id], 1u);
         tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
-        if (tile >= P.tile_end)
+        if (tile >= H.tile_end)
             break;
-        freq_tile<SF, EMIS>(P, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, nslot, tile, lane);
+        // the cold half of the argument block, addressed inside the kernarg segment; made opaque per tile so
+        // that its loads stay in the tile's preamble instead of being hoisted (and kept live) above this loop
+        ColdPtr C = (ColdPtr) ((const RT_CONST_AS char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(FreqKArg, cold));
+        asm volatile("" : "+s"(C));
+        // likewise the flag word and the lane number: the dozens of wave-uniform predicates and lane masks derived
+        // from them are recomputed per tile (one instruction each) rather than parked in SGPRs across all tiles
+        unsigned hflags = H.flags;
+        int lane_t      = lane;
+        asm volatile("" : "+s"(hflags), "+v"(lane_t));
+        freq_tile<SF, EMIS>(H, hflags, C, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, tile, lane_t);
     }
     if (lds_iang) {
         __syncthreads();
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x) {
             const double v = lds_iang[c];
             if (v != 0.0)
-                unsafeAtomicAdd(&P.iang[c], v);
+                unsafeAtomicAdd(&H.iang[c], v);
         }
     }
 }

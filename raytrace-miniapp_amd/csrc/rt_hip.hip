@@ -253,6 +253,13 @@ struct rt_hip_plan {
     unsigned char *bad_dev = nullptr; // failing-ray marks of the checking repeat (plan_repeat_checked)
     size_t bad_rays        = 0;
     std::chrono::steady_clock::time_point t_created;
+    // frequency kernel arguments that are not part of DevParams (rt_device.h: FreqHot)
+    std::vector<const float *> gv_dev; // [N] lineshape table of every length on the device, entry 0 unused
+    const double *dv2_dev = nullptr;   // [Kp] 2 * beam.dv
+    bool gv_has_nan       = false;     // host scan of the lineshape tables (emission mode)
+    // the refractive-index tables and the segment length lie in the ranges under which the march's divisions
+    // need no scaling (rt_march.hip, template parameter BOUNDED); checked by rt_hip_plan_create
+    bool tables_bounded   = false;
 };
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
@@ -294,7 +301,46 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         cap = cap_blocks;
     const unsigned grid = (unsigned) (want < cap ? want : cap);
     if (grid > 0) {
-        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3(256), lds, stream, p->P, in_lds, nslot);
+        // the kernel's own argument block (rt_device.h): hot = what the frequency loop reads, cold = what the
+        // per-ray preamble of a tile reads
+        const rt::DevParams &P = p->P;
+        rt::FreqKArg a;
+        memset(&a, 0, sizeof(a));
+        a.hot.gv0        = p->gv_dev.size() > 1 ? p->gv_dev[1] : nullptr;
+        a.hot.gv1        = p->gv_dev.size() > 2 ? p->gv_dev[2] : nullptr;
+        a.hot.gain       = P.gain;
+        a.hot.rec        = P.rec;
+        a.hot.image      = P.image;
+        a.hot.iang       = P.iang;
+        a.hot.ctl        = P.ctl;
+        a.hot.dv2        = p->dv2_dev;
+        a.hot.seed_fk    = P.has_seed ? P.seed.f[4] : nullptr;
+        a.hot.bad        = P.bad;
+        a.hot.scale      = P.scale;
+        a.hot.gs_cap     = P.gs_cap;
+        a.hot.K          = P.K;
+        a.hot.Kp         = P.Kp;
+        a.hot.L          = P.L;
+        a.hot.method     = P.method;
+        a.hot.rec_stride = P.rec_stride;
+        a.hot.n_rays     = (unsigned) P.rays.count;
+        a.hot.tile_begin = P.tile_begin;
+        a.hot.tile_end   = P.tile_end;
+        a.hot.freq_id    = P.freq_id;
+        a.hot.nslot      = nslot;
+        a.hot.nx         = P.beam.nx;
+        a.hot.ny         = P.beam.ny;
+        a.hot.n_ang      = P.beam.na * P.beam.nb;
+        a.hot.flags      = (P.exclusive ? rt::FQ_EXCLUSIVE : 0u) | (P.safe == 1 ? rt::FQ_SAFE_CHECK : 0u) |
+                      (P.safe == 2 ? rt::FQ_SAFE_SKIP : 0u) | (P.exact_emis ? rt::FQ_EXACT_EMIS : 0u) |
+                      (P.has_seed ? rt::FQ_HAS_SEED : 0u) | (P.probe_on ? rt::FQ_PROBE : 0u) |
+                      (p->gv_has_nan ? rt::FQ_GV_NAN : 0u) | (in_lds ? rt::FQ_IANG_LDS : 0u) |
+                      ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u);
+        a.cold.beam  = P.beam;
+        a.cold.seed  = P.seed;
+        a.cold.rays  = P.rays;
+        a.cold.probe = P.probe;
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3(256), lds, stream, a);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
@@ -494,13 +540,16 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     bthr = env_unsigned("RT_HIP_MARCH_THREADS", bthr, 64, lds_tab ? 1024 : 256) / 64 * 64; // occupancy experiments
     const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
     int per_cu          = 0;
-    if (lds_tab) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt::rt_march_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) mlds));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_march_kernel<true>, (int) bthr, mlds));
-    } else {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt::rt_march_kernel<false>, (int) bthr, mlds));
-    }
+    // the integrator's divisions without range bookkeeping where the tables and the step factor allow it
+    // (rt_math.h, fdiv_nr; RT_HIP_MARCH_IEEE=1 forces the full IEEE sequences)
+    static const bool force_ieee = getenv("RT_HIP_MARCH_IEEE") != nullptr;
+    const bool bounded = p->tables_bounded && p->P.c_h3 >= 1e-8f && !force_ieee;
+    using march_fn = void (*)(const rt::DevParams);
+    const march_fn kernel = lds_tab ? (bounded ? rt::rt_march_kernel<true, true> : rt::rt_march_kernel<true, false>)
+                                    : (bounded ? rt::rt_march_kernel<false, true> : rt::rt_march_kernel<false, false>);
+    if (lds_tab)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) mlds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int) bthr, mlds));
     if (per_cu < 1)
         per_cu = 1;
     unsigned long long want = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
@@ -568,10 +617,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         p->P.ray_begin = (unsigned) b;
         p->P.ray_end   = (unsigned) e;
         p->P.launch_id = c;
-        if (lds_tab)
-            hipLaunchKernelGGL(rt::rt_march_kernel<true>, dim3(grid), dim3(bthr), mlds, stream, p->P);
-        else
-            hipLaunchKernelGGL(rt::rt_march_kernel<false>, dim3(grid), dim3(bthr), mlds, stream, p->P);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(bthr), mlds, stream, p->P);
         HIP_TRY(hipGetLastError());
     }
     p->host_rays = nullptr; // consumed: the list is on the device now
@@ -730,6 +776,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     const int Kp = (K + 3) & ~3; // rows padded to four frequencies (DevParams::Kp)
     for (int i = 1; i < N; i++) {
         const size_t cells = (size_t) gain[i].Nx * (size_t) gain[i].Ny;
+        if (cells * (size_t) Kp * sizeof(float) >= (1ull << 32)) { // the frequency kernel addresses rows with 32 bits
+            delete p;
+            return fail_arg("rt_hip_plan_create: a lineshape table of 4 GiB or more is not supported");
+        }
         if (Kp == K) {
             off_gv[(size_t) i] = ab.put(gain[i].gv, sizeof(float) * cells * (size_t) K);
         } else {
@@ -745,6 +795,11 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     const size_t off_bb  = ab.put(beam->b, sizeof(double) * (size_t) beam->nb);
     const size_t off_bdv = ab.reserve(sizeof(double) * (size_t) Kp);
     memcpy(ab.host.data() + off_bdv, beam->dv, sizeof(double) * (size_t) beam->nv);
+    const size_t off_bdv2 = ab.reserve(sizeof(double) * (size_t) Kp); // 2 * dv (exact), RayTraceImageCPU.cpp:66
+    for (int k = 0; k < beam->nv; k++) {
+        const double d2 = 2.0 * beam->dv[k];
+        memcpy(ab.host.data() + off_bdv2 + sizeof(double) * (size_t) k, &d2, sizeof(double));
+    }
     size_t off_sx[5] = { 0 }, off_sf[5] = { 0 };
     if (seed) {
         for (int i = 0; i < 5; i++) {
@@ -769,7 +824,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     // march blob: headers + grids + fused corner nodes of every length, copied to LDS
     // verbatim by rt_march_kernel<true>
     std::vector<unsigned char> blob(align_up(sizeof(rt::BlobGain) * (size_t) N, 16));
-    bool tiny_spacing = false, bad_index = false;
+    bool tiny_spacing = false, bad_index = false, all_bounded = true;
     for (int i = 1; i < N; i++) {
         const rt_gain &g  = gain[i];
         const size_t npix = (size_t) g.Nx * (size_t) g.Ny;
@@ -827,7 +882,34 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             nd[c].E0 = g.E0 ? g.E0[c] : 0.0f;
         }
         memcpy(blob.data() + sizeof(rt::BlobGain) * (size_t) i, &h, sizeof(h));
+        // Ranges for the short division sequences of the integrator (rt_math.h, fdiv_nr): with dn = the largest
+        // difference of the index between neighbouring nodes, a step sees n within [min n - dn, max n + dn]
+        // (bilinear value on the cell box with its 10 % margin, plus |r| < 0.1 w times a gradient of at most
+        // 1.3 dn / w per axis) and index gradients of at most 1.3 dn / min(w).
+        {
+            double n_lo = g.n[0], n_hi = g.n[0], dn = 0.0, w_min = g.x[1] - g.x[0];
+            for (int k = 1; k < g.Nx; k++)
+                w_min = std::min(w_min, g.x[k] - g.x[k - 1]);
+            for (int k = 1; k < g.Ny; k++)
+                w_min = std::min(w_min, g.y[k] - g.y[k - 1]);
+            for (int iy = 0; iy < g.Ny; iy++) {
+                const double *row = g.n + (size_t) iy * (size_t) g.Nx;
+                for (int ix = 0; ix < g.Nx; ix++) {
+                    n_lo = std::min(n_lo, row[ix]);
+                    n_hi = std::max(n_hi, row[ix]);
+                    if (ix > 0)
+                        dn = std::max(dn, fabs(row[ix] - row[ix - 1]));
+                    if (iy > 0)
+                        dn = std::max(dn, fabs(row[ix] - row[ix - g.Nx]));
+                }
+            }
+            if (!(n_lo - dn >= 0.25 && n_hi + dn <= 4.0 && dn / w_min <= 1e12 && w_min >= 1e-12))
+                all_bounded = false;
+        }
     }
+    if (!(beam->dz >= 1e-12 && beam->dz <= 1e12))
+        all_bounded = false;
+    p->tables_bounded = all_bounded;
     if (tiny_spacing) {
         delete p;
         return fail_arg("rt_hip_plan_create: gain grid not strictly increasing, or spacing below 1e-30");
@@ -851,9 +933,12 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     p->arena_bytes = align_up(ab.host.size(), 256);
     PLAN_TRY(pool_alloc(device, (void **) &p->arena, p->arena_bytes));
     unsigned char *A = p->arena;
+    p->gv_dev.assign((size_t) N, nullptr);
     for (int i = 1; i < N; i++) {
-        dg[(size_t) i].gv = reinterpret_cast<const float *>(A + off_gv[(size_t) i]);
+        dg[(size_t) i].gv    = reinterpret_cast<const float *>(A + off_gv[(size_t) i]);
+        p->gv_dev[(size_t) i] = dg[(size_t) i].gv;
     }
+    p->dv2_dev = reinterpret_cast<const double *>(A + off_bdv2);
     memcpy(ab.host.data() + off_gain, dg.data(), sizeof(rt::DevGain) * (size_t) N);
     PLAN_TRY(hipMemcpy(p->arena, ab.host.data(), ab.host.size(), hipMemcpyHostToDevice));
     lap("alloc + upload");
@@ -926,13 +1011,16 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             for (int i = 1; i < N; i++) {
                 const size_t n    = (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K;
                 const uint32_t *u = reinterpret_cast<const uint32_t *>(gain[i].gv);
-                uint32_t m        = 0;
+                uint32_t m = 0, mall = 0;
                 for (size_t c = 0; c < n; c++) {
                     uint32_t a = u[c] & 0x7fffffffu;
+                    mall       = a > mall ? a : mall;
                     a          = a < 0x7f800000u ? a : 0u; // inf and NaN do not count
                     m          = a > m ? a : m;
                 }
                 umax = m > umax ? m : umax;
+                if (mall > 0x7f800000u) // a NaN: the frequency kernel then tests every value it reads
+                    p->gv_has_nan = true;
             }
             memcpy(&wmax, &umax, sizeof(wmax));
         }

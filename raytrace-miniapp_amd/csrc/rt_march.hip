@@ -229,15 +229,28 @@ extern "C" __global__ void __launch_bounds__(256) rt_seed_tab_kernel(const DevSe
     }
 }
 
-// rt_hip_selftest: inv_norm against the IEEE sequence, bit for bit, for every float of its
-// shortcut range and every 256th bit pattern elsewhere
+// rt_hip_selftest: the two exact shortcuts of the march against the IEEE sequences, bit for bit, on the device
+// itself: inv_norm for every float of its shortcut range and every 256th bit pattern elsewhere; fdiv_nr /
+// fdiv_one_nr against `/` for every divisor of [0.25, 4) (1/n) and for 2^28 pseudo-random operand pairs drawn
+// log-uniformly from the ranges the integrator's step candidates can take under DevParams-bounded tables
+// (dividend 2^-84 .. 1, divisor 2^-78 .. 2^44, quotient normal, exponents less than 96 apart).
+__device__ __forceinline__ unsigned selftest_hash(unsigned x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
 extern "C" __global__ void __launch_bounds__(256) rt_selftest_kernel(unsigned long long *counts)
 {
     const unsigned lo = 0x3f700000u, hi = 0x3f880000u; // [0.9375, 1.0625)
     const unsigned n_fast = hi - lo, n_other = 1u << 24;
     unsigned long long checked = 0, bad = 0;
-    for (unsigned long long t = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; t < (unsigned long long) n_fast + n_other;
-         t += (unsigned long long) gridDim.x * blockDim.x) {
+    const unsigned long long tid = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nth = (unsigned long long) gridDim.x * blockDim.x;
+    for (unsigned long long t = tid; t < (unsigned long long) n_fast + n_other; t += nth) {
         const unsigned u = t < n_fast ? lo + (unsigned) t : (unsigned) (t - n_fast) << 8;
         float q          = __uint_as_float(u);
         const float a    = inv_norm(q);
@@ -246,6 +259,30 @@ extern "C" __global__ void __launch_bounds__(256) rt_selftest_kernel(unsigned lo
         checked++;
         if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b))
             bad++;
+    }
+    // 1 / n for every float n of [0.25, 4)
+    for (unsigned long long t = tid; t < (4ull << 23); t += nth) {
+        float n       = __uint_as_float(0x3e800000u + (unsigned) t);
+        const float a = fdiv_one_nr(n);
+        asm volatile("" : "+v"(n));
+        const float b = 1.0f / n;
+        checked++;
+        bad += __float_as_uint(a) != __float_as_uint(b) ? 1 : 0;
+    }
+    // the step candidates: dividend 2^(ea) * [1, 2), divisor 2^(eb) * [1, 2), ea in [-84, -1], eb in [-78, 43],
+    // pairs whose exponents are 96 or more apart or whose quotient could be subnormal are skipped (never the minimum)
+    for (unsigned long long t = tid; t < (1ull << 28); t += nth) {
+        const unsigned h0 = selftest_hash((unsigned) t * 2u + 1u), h1 = selftest_hash((unsigned) t * 2u + 0x9e3779b9u);
+        const int ea = -84 + (int) (h0 % 84u), eb = -78 + (int) (h1 % 122u);
+        if (ea - eb >= 96 || eb - ea >= 96 || ea - eb < -120)
+            continue;
+        float x = __uint_as_float(((unsigned) (ea + 127) << 23) | (selftest_hash(h0) & 0x7fffffu));
+        float y = __uint_as_float(((unsigned) (eb + 127) << 23) | (selftest_hash(h1) & 0x7fffffu));
+        const float a = fdiv_nr(x, y);
+        asm volatile("" : "+v"(x), "+v"(y));
+        const float b = x / y;
+        checked++;
+        bad += __float_as_uint(a) != __float_as_uint(b) ? 1 : 0;
     }
     atomicAdd(&counts[0], checked);
     atomicAdd(&counts[1], bad);
@@ -289,7 +326,10 @@ __device__ __forceinline__ int guess_interval(int n, float g0, float inv_h, floa
     return u < 1 ? 1 : (u > last ? last : u);
 }
 
-template <bool LDS_TAB>
+// BOUNDED: rt_hip_plan_create has verified the table and step-size ranges under which the integrator's five
+// divisions per step need none of the scaling / fix-up instructions of an IEEE division (rt_math.h, fdiv_nr);
+// otherwise (exotic tables) every division is the full sequence.  Both give the reference's floats.
+template <bool LDS_TAB, bool BOUNDED>
 __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -516,37 +556,76 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     const Interval *ivy = reinterpret_cast<const Interval *>(tab + G.off_iy);
                     // (records are addressed by 32-bit byte offsets from the start of the blob: no
                     // 64-bit multiplies for what is an LDS address)
-                    auto interval_at = [&](int off, int u) {
-                        return *reinterpret_cast<const Interval *>(tab + ((unsigned) off + (unsigned) u * (unsigned) sizeof(Interval)));
-                    };
-                    auto node_at = [&](int c) {
+                    // One round of gathers per cell: two 48-byte interval records and four 16-byte corner nodes, as
+                    // ten 16-byte LDS reads issued together.  (Left to itself the compiler reads the tail of an
+                    // interval record as ds_read_b96 and a node as b64 + b32 + b32; measured issue cost per LDS
+                    // instruction: b32 / b64 5, b128 10, b96 20 VALU-equivalent ticks -- tools/ubench.)  The
+                    // empty asm statements keep the 16-byte reads whole.
+                    auto read16 = [&](unsigned byte_off) {
 #ifdef RT_ABL_NODES_GLOBAL
-                        return *reinterpret_cast<const Node *>(P.blob + ((unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node)));
+                        return *reinterpret_cast<const uint4 *>(P.blob + byte_off);
 #else
-                        return *reinterpret_cast<const Node *>(tab + ((unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node)));
+                        return *reinterpret_cast<const uint4 *>(tab + byte_off);
 #endif
+                    };
+                    auto f64_of = [](unsigned lo, unsigned hi) { return __hiloint2double((int) hi, (int) lo); };
+                    auto gather = [&](int k1, int k2, int c, Interval &X, Interval &Y, Node &n00, Node &n10, Node &n01, Node &n11) {
+                        const unsigned ox = (unsigned) G.off_ix + (unsigned) k1 * (unsigned) sizeof(Interval);
+                        const unsigned oy = (unsigned) G.off_iy + (unsigned) k2 * (unsigned) sizeof(Interval);
+                        const unsigned oa = (unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node);
+                        const unsigned ob = oa + (unsigned) G.Nx * (unsigned) sizeof(Node);
+                        uint4 x0 = *reinterpret_cast<const uint4 *>(tab + ox), x1 = *reinterpret_cast<const uint4 *>(tab + ox + 16),
+                              x2 = *reinterpret_cast<const uint4 *>(tab + ox + 32);
+                        uint4 y0 = *reinterpret_cast<const uint4 *>(tab + oy), y1 = *reinterpret_cast<const uint4 *>(tab + oy + 16),
+                              y2 = *reinterpret_cast<const uint4 *>(tab + oy + 32);
+                        uint4 q0 = read16(oa), q1 = read16(oa + 16), q2 = read16(ob), q3 = read16(ob + 16);
+                        asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w),
+                                          "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(y0.x), "+v"(y0.y), "+v"(y0.z), "+v"(y0.w),
+                                          "+v"(y1.x), "+v"(y1.y), "+v"(y1.z), "+v"(y1.w), "+v"(y2.x), "+v"(y2.y), "+v"(y2.z), "+v"(y2.w));
+                        X.lo = f64_of(x0.x, x0.y);
+                        X.hi = f64_of(x0.z, x0.w);
+                        X.rh = f64_of(x1.x, x1.y);
+                        X.rw = f64_of(x1.z, x1.w);
+                        X.w  = __uint_as_float(x2.x);
+                        X.b_lo = __uint_as_float(x2.y);
+                        X.b_hi = __uint_as_float(x2.z);
+                        Y.lo = f64_of(y0.x, y0.y);
+                        Y.hi = f64_of(y0.z, y0.w);
+                        Y.rh = f64_of(y1.x, y1.y);
+                        Y.rw = f64_of(y1.z, y1.w);
+                        Y.w  = __uint_as_float(y2.x);
+                        Y.b_lo = __uint_as_float(y2.y);
+                        Y.b_hi = __uint_as_float(y2.z);
+                        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                                          "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+                        auto unpack = [&](const uint4 &q) {
+                            Node nd;
+                            nd.n  = f64_of(q.x, q.y);
+                            nd.g0 = __uint_as_float(q.z);
+                            nd.E0 = __uint_as_float(q.w);
+                            return nd;
+                        };
+                        n00 = unpack(q0);
+                        n10 = unpack(q1);
+                        n01 = unpack(q2);
+                        n11 = unpack(q3);
                     };
                     const float ya      = mirror ? fabsf(py) : py;
                     const double pxd = (double) px, yad = (double) ya;
                     // one round of gathers on the guessed cell: two interval records, four nodes
                     int k1     = guess_interval(G.Nx, G.x0f, G.inv_hxf, px);
                     int k2     = guess_interval(G.Ny, G.y0f, G.inv_hyf, ya);
-                    Interval X = interval_at(G.off_ix, k1), Y = interval_at(G.off_iy, k2);
                     c00        = (k1 - 1) + (k2 - 1) * G.Nx;
-                    Node a00 = node_at(c00), a10 = node_at(c00 + 1);
-                    Node a01 = node_at(c00 + G.Nx), a11 = node_at(c00 + G.Nx + 1);
+                    Interval X, Y;
+                    Node a00, a10, a01, a11;
+                    gather(k1, k2, c00, X, Y, a00, a10, a01, a11);
                     const bool ok = ((k1 == 1) | (X.lo < pxd)) & ((k1 == G.Nx - 1) | (X.hi >= pxd)) &
                                     ((k2 == 1) | (Y.lo < yad)) & ((k2 == G.Ny - 1) | (Y.hi >= yad));
                     if (!ok) {
                         k1  = bisect_interval(ivx, G.Nx, pxd);
                         k2  = bisect_interval(ivy, G.Ny, yad);
-                        X   = interval_at(G.off_ix, k1);
-                        Y   = interval_at(G.off_iy, k2);
                         c00 = (k1 - 1) + (k2 - 1) * G.Nx;
-                        a00 = node_at(c00);
-                        a10 = node_at(c00 + 1);
-                        a01 = node_at(c00 + G.Nx);
-                        a11 = node_at(c00 + G.Nx + 1);
+                        gather(k1, k2, c00, X, Y, a00, a10, a01, a11);
                     }
                     f00       = (float) a00.n;
                     f10       = (float) a10.n;
@@ -667,9 +746,12 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 #else
 #define RT_FDIV(a, b) ((a) / (b))
 #endif
-                const float rn = RT_FDIV(1.0f, n); // one IEEE division, three exact quotients
+                // one IEEE division, three exact quotients
+                const float rn = BOUNDED ? fdiv_one_nr(n) : RT_FDIV(1.0f, n);
                 float a0 = sx * gxn + sy * gyn + 1e-12f;
-                float t  = div_by_recip_signed(a0, n, rn);
+                // (BOUNDED: a0 is never -0 -- x + 1e-12f is +0 or non-zero -- and rn > 0, so the corrected
+                // quotient has the sign of a0 without the sign copy)
+                float t  = BOUNDED ? fmaf(fmaf(-n, a0 * rn, a0), rn, a0 * rn) : div_by_recip_signed(a0, n, rn);
                 float qx = div_by_recip_signed(gxn, n, rn);
                 float qy = div_by_recip_signed(gyn, n, rn);
 #ifndef RT_ABL_NOGUARD
@@ -697,14 +779,27 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 float fx = qx - sx * t;
                 float fy = qy - sy * t;
                 float fz = -sz * t;
-                float h  = RT_FDIV(P.c_h1, fabsf(t)); // c * 0.1f / |t|
-                h        = h < dzcap ? h : dzcap;
-                float h2 = RT_FDIV(1.0001f * (lim2 - fabsf(rz)), fabsf(sz));
-                float h3 = RT_FDIV(P.c_h3 * (fabsf(sx) + 5e-4f), (fabsf(fx) + 1e-8f)); // c * 0.05f * ...
-                float h4 = RT_FDIV(P.c_h3 * (fabsf(sy) + 5e-4f), (fabsf(fy) + 1e-8f));
-                h        = h < h2 ? h : h2;
-                h        = h < h3 ? h : h3;
-                h        = h < h4 ? h : h4;
+                float h;
+                if (BOUNDED) {
+                    // The step candidates (Helper.h:288-297) without the range bookkeeping of an IEEE division
+                    // (fdiv_nr, rt_math.h): exact wherever a candidate can be the minimum; a candidate that the
+                    // short sequence gets wrong is huge, infinite or NaN on both paths (its true value is above
+                    // dzcap), and the NaN-dropping minimum below passes over it as the `<` chain passes over +inf.
+                    const float h1 = fdiv_nr(P.c_h1, fabsf(t)); // c * 0.1f / |t|
+                    const float h2 = fdiv_nr(1.0001f * (lim2 - fabsf(rz)), fabsf(sz));
+                    const float h3 = fdiv_nr(P.c_h3 * (fabsf(sx) + 5e-4f), (fabsf(fx) + 1e-8f)); // c * 0.05f * ...
+                    const float h4 = fdiv_nr(P.c_h3 * (fabsf(sy) + 5e-4f), (fabsf(fy) + 1e-8f));
+                    h = fmin_nan_drop(fmin_nan_drop(h1, dzcap), fmin_nan_drop(h2, fmin_nan_drop(h3, h4)));
+                } else {
+                    h        = RT_FDIV(P.c_h1, fabsf(t)); // c * 0.1f / |t|
+                    h        = h < dzcap ? h : dzcap;
+                    float h2 = RT_FDIV(1.0001f * (lim2 - fabsf(rz)), fabsf(sz));
+                    float h3 = RT_FDIV(P.c_h3 * (fabsf(sx) + 5e-4f), (fabsf(fx) + 1e-8f)); // c * 0.05f * ...
+                    float h4 = RT_FDIV(P.c_h3 * (fabsf(sy) + 5e-4f), (fabsf(fy) + 1e-8f));
+                    h        = h < h2 ? h : h2;
+                    h        = h < h3 ? h : h3;
+                    h        = h < h4 ? h : h4;
+                }
                 float ht = h * t;
                 const float R3 = 1.0f / 3.0f, R6 = 1.0f / 6.0f, R12 = 1.0f / 12.0f; // RN(1/b), folded
                 float c1 = 0.5f * h * h * (1.0f - div_by_recip<true>(ht, 3.0f, R3) + div_by_recip<true>(ht * ht, 12.0f, R12));

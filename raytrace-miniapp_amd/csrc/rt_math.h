@@ -167,6 +167,38 @@ template <bool TINY_OK = false> __device__ __forceinline__ double div_by_recip(d
     return c;
 }
 
+// a / b as the hardware's IEEE sequence computes it (v_div_scale x2, v_rcp, five fma/mul, v_div_fmas,
+// v_div_fixup) minus the scaling and fix-up instructions: the same reciprocal, Newton step, quotient and two
+// residual corrections, hence the same float, whenever v_div_scale would leave both operands unscaled and
+// v_div_fixup would pass the result through -- normal operands whose exponents differ by less than 96, a
+// dividend of at least 2^-102, a divisor below 2^126, a normal quotient.  rt_hip_plan_create establishes those
+// ranges for the integrator's divisions from the tables (DevParams::bounded); rt_hip_selftest compares the two
+// sequences on the device over the ranges it relies on.
+__device__ __forceinline__ float fdiv_nr(float a, float b)
+{
+    float r       = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, r, 1.0f);
+    r             = fmaf(e, r, r);
+    float q       = a * r;
+    q             = fmaf(fmaf(-b, q, a), r, q);
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+__device__ __forceinline__ float fdiv_one_nr(float b) // 1.0f / b, likewise (the quotient a * r is r itself)
+{
+    float r       = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, r, 1.0f);
+    r             = fmaf(e, r, r);
+    const float q = fmaf(fmaf(-b, r, 1.0f), r, r);
+    return fmaf(fmaf(-b, q, 1.0f), r, q);
+}
+// min(a, b) that drops a NaN operand (v_min_f32, IEEE minNum): one instruction instead of compare + select
+__device__ __forceinline__ float fmin_nan_drop(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Helper.h:153-158
 __device__ __forceinline__ float lerp2(float u, float v, float f00, float f10, float f01, float f11)
 {

@@ -64,6 +64,12 @@ BODY(and_b32, "v_and_b32 %4, %4, %9\n v_and_b32 %4, %4, %9\n")
 BODY(fma_sgpr, "v_fma_f32 %0, %0, s10, %6\n v_fma_f32 %1, %1, s11, %6\n")
 BODY(absfma, "v_fma_f32 %0, |%0|, %5, %6\n v_fma_f32 %1, -%1, %5, %6\n")
 BODY(dsread, "ds_read_b128 v[20:23], %4\n ds_read_b128 v[24:27], %4 offset:16\n")
+BODY(dsread32, "ds_read_b32 v20, %4\n ds_read_b32 v24, %4 offset:16\n")
+BODY(dsread64, "ds_read_b64 v[20:21], %4\n ds_read_b64 v[24:25], %4 offset:16\n")
+BODY(dsread96, "ds_read_b96 v[20:22], %4\n ds_read_b96 v[24:26], %4 offset:16\n")
+BODY(min32, "v_min_f32 %0, %0, %5\n v_min_f32 %1, %1, %6\n")
+BODY(cmp_nop_cnd, "v_cmp_lt_f32 vcc, %0, %5\n s_nop 1\n v_cndmask_b32 %1, %5, %6, vcc\n")
+BODY(readlane, "v_readlane_b32 s10, %0, 3\n v_readlane_b32 s11, %1, 5\n")
 
 struct K { const char *name; void (*fn)(unsigned long long *, int); int per_rep; };
 int main()
@@ -72,7 +78,7 @@ int main()
 #define E(n, c) { #n, k_##n, c }
         E(fma32_dep, 1), E(fma32_ind, 2), E(mul32, 2), E(cndmask, 2), E(cmp32, 2), E(mov, 2), E(min3, 2), E(bfi, 2), E(addu, 2),
         E(mullo, 2), E(rcp32, 2), E(rsq32, 2), E(divscale, 2), E(divfix, 2), E(divfmas, 2), E(fma64, 2), E(mul64, 2), E(add64, 2),
-        E(cvt64_32, 2), E(cvt32_64, 2), E(cmp64, 2), E(pkfma, 2), E(salu, 2), E(mix_fs, 2), E(cnd_e64,2), E(cnd_ind,2), E(cnd_ind64,2), E(snop,2), E(swait,2), E(saveexec,4), E(br_nt,8), E(br_tk,2), E(cmp_cnd,2), E(cmp_e64,2), E(and_b32,2), E(fma_sgpr,2), E(absfma,2), E(dsread,2) };
+        E(cvt64_32, 2), E(cvt32_64, 2), E(cmp64, 2), E(pkfma, 2), E(salu, 2), E(mix_fs, 2), E(cnd_e64,2), E(cnd_ind,2), E(cnd_ind64,2), E(snop,2), E(swait,2), E(saveexec,4), E(br_nt,8), E(br_tk,2), E(cmp_cnd,2), E(cmp_e64,2), E(and_b32,2), E(fma_sgpr,2), E(absfma,2), E(dsread,2), E(dsread32,2), E(dsread64,2), E(dsread96,2), E(min32,2), E(cmp_nop_cnd,3), E(readlane,2) };
     unsigned long long *d;
     hipMalloc(&d, 4096 * 16 * 8);
     const int iters = 500;
