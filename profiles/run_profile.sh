@@ -5,12 +5,15 @@
 #   pass 3: --pmc WRITE_SIZE                -> HBM write side (TCC, 2 slots)
 #   pass 4/5: --pmc SQ counters             -> instruction counts / issue utilisation, shader clock
 #   pass 6-8: the same trace / FETCH / WRITE passes for BASELINE config 5 (--workload config5)
+#   pass 9-11: and for the seeded half of config 3 (--workload seed_medium)
+#   usage: bash profiles/run_profile.sh <tag> <steps> <git head the snapshot was taken at>
 # PMC passes are separate runs with no tracing domains beside --kernel-trace
 # (MI355X_MICROARCH.md "HBM", "rocprofv3 PMC slots").  Outputs land under
 # gpurun_out/prof_<tag>/ ; summarise with profiles/summarize.py.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 STEPS=${2:-20}
+HEAD=${3:-unknown}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -32,4 +35,10 @@ echo "c5 trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/c5_fetch" -o pmc -- $C5 > "$OUT/c5_fetch.log" 2>&1 || echo "c5 fetch failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/c5_write" -o pmc -- $C5 > "$OUT/c5_write.log" 2>&1 || echo "c5 write failed"
 echo "c5 pmc done"
-python3 profiles/summarize.py "$OUT" "$TAG" > "$OUT/summary.json"; tail -3 "$OUT/bench_trace.log"
+SM="python3 bench.py --workload seed_medium --steps 3 --warmup 1 --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sm_trace" -o trace -- $SM > "$OUT/sm_trace.log" 2>&1 || echo "sm trace failed"
+echo "sm trace done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/sm_fetch" -o pmc -- $SM > "$OUT/sm_fetch.log" 2>&1 || echo "sm fetch failed"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/sm_write" -o pmc -- $SM > "$OUT/sm_write.log" 2>&1 || echo "sm write failed"
+echo "sm pmc done"
+python3 profiles/summarize.py "$OUT" "$TAG" "$HEAD" > "$OUT/summary.json"; tail -3 "$OUT/bench_trace.log"

@@ -67,10 +67,46 @@ def pmc(root, sub):
     return out
 
 
+def kernel_source_hash():
+    """The same hash bench.py computes: sha1 over csrc/*.hip and *.h (bench.py quotes these counters only while
+    the kernel sources are the ones they were measured on)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    csrc = Path(__file__).resolve().parent.parent / "raytrace-miniapp_amd" / "csrc"
+    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def workload_traffic(root, here, tag, prefix, name):
+    """kernel times and HBM bytes per step of a side workload (bench.py --workload <name>)"""
+    t = kernel_stats(root, here / f"{tag}_{name}_kernel_stats.csv", f"{prefix}_trace")
+    f, w = pmc(root, f"{prefix}_fetch"), pmc(root, f"{prefix}_write")
+    if not t:
+        return None
+    rec = {"kernel_trace": t, "kernels": {}}
+    tot = 0.0
+    for k in KERNELS:
+        fs = f.get(k, {}).get("avg", {}).get("FETCH_SIZE")
+        ws = w.get(k, {}).get("avg", {}).get("WRITE_SIZE")
+        if fs is None or ws is None:
+            continue
+        rd, wr = fs * 1024.0 * 2.0, ws * 1024.0
+        rec["kernels"][k] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr,
+                             "hbm_bytes_per_launch": rd + wr}
+        tot += rd + wr
+    if rec["kernels"]:
+        rec["hbm_bytes_per_step"] = tot
+    return rec
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     here = Path(__file__).resolve().parent
-    out = {"tag": tag, "kernels": list(KERNELS), "kernel_trace": kernel_stats(root, here / f"{tag}_kernel_stats.csv")}
+    out = {"tag": tag, "git_head": sys.argv[3] if len(sys.argv) > 3 else None, "kernel_source_hash": kernel_source_hash(),
+           "kernels": list(KERNELS), "kernel_trace": kernel_stats(root, here / f"{tag}_kernel_stats.csv")}
     fetch, write, sq = pmc(root, "pmc_fetch"), pmc(root, "pmc_write"), pmc(root, "pmc_sq")
     out["pmc_fetch"], out["pmc_write"], out["pmc_sq"] = fetch, write, sq
     hbm = {}
@@ -97,28 +133,16 @@ def main():
             clocks.append(gui / 8.0 / (kt[k]["avg_ns"] * 1e-9))
     if clocks:
         out["shader_clock_hz"] = sum(clocks) / len(clocks)
-    # BASELINE config 5 (bench.py --workload config5): kernel times and HBM bytes per step
-    c5t = kernel_stats(root, here / f"{tag}_config5_kernel_stats.csv", "c5_trace")
-    c5f, c5w = pmc(root, "c5_fetch"), pmc(root, "c5_write")
-    if c5t:
-        c5 = {"kernel_trace": c5t, "kernels": {}}
-        tot = 0.0
-        for k in KERNELS:
-            fs = c5f.get(k, {}).get("avg", {}).get("FETCH_SIZE")
-            ws = c5w.get(k, {}).get("avg", {}).get("WRITE_SIZE")
-            if fs is None or ws is None:
-                continue
-            rd, wr = fs * 1024.0 * 2.0, ws * 1024.0
-            c5["kernels"][k] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr,
-                                "hbm_bytes_per_launch": rd + wr}
-            tot += rd + wr
-        if c5["kernels"]:
-            c5["hbm_bytes_per_step"] = tot
-        out["config5"] = c5
+    # BASELINE config 5 and the seeded half of config 3 (bench.py --workload config5 / seed_medium)
+    for prefix, name in (("c5", "config5"), ("sm", "seed_medium")):
+        rec = workload_traffic(root, here, tag, prefix, name)
+        if rec:
+            out[name] = rec
     (here / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1))
     if hbm:
         (here / "traffic_latest.json").write_text(json.dumps(
-            {"tag": tag, "kernels": {k: v["hbm_bytes_per_launch"] for k, v in hbm.items()}, "detail": hbm}, indent=1))
+            {"tag": tag, "git_head": out["git_head"], "kernel_source_hash": out["kernel_source_hash"],
+             "kernels": {k: v["hbm_bytes_per_launch"] for k, v in hbm.items()}, "detail": hbm}, indent=1))
     print(json.dumps(out, indent=1))
 
 

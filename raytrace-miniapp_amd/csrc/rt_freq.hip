@@ -146,7 +146,7 @@ __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, cons
     const double L2E   = 369.3299304675746;     // 256 / ln 2
     const double LN2_N = 0.0027076061740622863; // ln 2 / 256
     const double MAGIC = 0x1.8p52;              // adding it leaves rint(.) in the low mantissa bits
-    double r[VEC], T[VEC];
+    double rq[VEC], T[VEC];
     int m[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -154,18 +154,26 @@ __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, cons
         double t       = fma(x, L2E, MAGIC);
         const int n    = __double2loint(t);
         t -= MAGIC;
-        r[j] = fma(-t, LN2_N, x);
-        T[j] = tab[n & (EXP_TAB - 1)];
-        m[j] = n >> 8;
+        rq[j] = fma(-t, LN2_N, x);
+        T[j]  = tab[n & (EXP_TAB - 1)];
+        m[j]  = n >> 8;
     }
+    // the four polynomials first: twelve instructions that need only r, while the table reads travel
+    // (scheduled freely, the compiler waits for the first read four instructions after issuing it; measured:
+    // no difference at four waves per SIMD -- the kernel is bound by instruction issue, not by this latency)
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-        double q = fma(r[j], 1.0 / 6.0, 0.5);
-        q        = fma(r[j], q, 1.0);
+        double q = fma(rq[j], 1.0 / 6.0, 0.5);
+        q        = fma(rq[j], q, 1.0);
+        rq[j] *= q;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
         int hi; // exponent field += m in one v_lshl_add_u32 (the compiler's own choice is shift, mask, add)
         asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"(m[j]), "v"(__double2hiint(T[j])));
         const double S   = __hiloint2double(hi, __double2loint(T[j]));
-        const double em1 = fma(S, r[j] * q, S - 1.0);
+        const double em1 = fma(S, rq[j], S - 1.0);
         Iv[j]            = fma(em1, Iv[j] + rs, Iv[j]);
     }
 }

@@ -563,7 +563,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
     ch                    = ch < 64 ? 64 : (ch > 192 ? 192 : ch);
     p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
-    p->P.chunk = env_unsigned("RT_HIP_MARCH_CHUNK", p->P.chunk, 1, 1u << 20); // tuning
+    p->P.chunk = env_unsigned("RT_HIP_MARCH_CHUNK", p->P.chunk, 1, 4096); // tuning
     // lanes that must wait for block [A] of the march before it runs (swept 1 ... 40 on the 6.4 M-ray
     // stand-in: 2.36 ms at 1, flat optimum 2.12 ms at 8 ... 24, 2.63 ms at 40)
     p->P.park    = env_unsigned("RT_HIP_MARCH_PARK", 12, 1, 64);
@@ -1036,8 +1036,10 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
 
 // rt_hip_image_loop only: the list stays on the host until the run, which uploads it in slices
 // beside the march (the caller's buffer outlives the call, the plan does not)
-// the kernels index rays with 32 bits, and the march reserves up to 512 indices past the end
-constexpr size_t MAX_LIST_RAYS = 0xffffffffull - 512;
+// the kernels index rays with 32 bits, and the march's ray counter overshoots the end: every wave of the
+// persistent grid adds one more reservation after the rays have run out (at most 8192 waves x 4096 rays, the
+// cap of RT_HIP_MARCH_CHUNK) -- the counter must not wrap
+constexpr size_t MAX_LIST_RAYS = 0xffffffffull - (1ull << 26);
 
 static int plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
 {

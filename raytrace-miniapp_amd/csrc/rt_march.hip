@@ -760,6 +760,10 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 // below the bound only where a lane holds an exact zero (index gradient of a uniform
                 // region; the quotient 0 is right as it is) or, once in a blue moon, such a dividend.
                 if (__ballot(fminf(fminf(fabsf(a0), fabsf(gxn)), fabsf(gyn)) < 1e-29f) != 0ull) {
+#ifdef RT_INSTRUMENT
+                    if (lane == (int) __ffsll((long long) __ballot(1)) - 1)
+                        atomicAdd(&g_inst[6], 1ull); // wave-level entries of the tiny-dividend block
+#endif
                     if (fabsf(a0) < 1e-29f && a0 != 0.0f) {
                         asm volatile("" : "+v"(a0));
                         t = a0 / n;

@@ -19,3 +19,4 @@ for name, p in cases.items():
     for i, lab in enumerate(("inner", "cross", "cell ")):
         w, a = v[2 * i], v[2 * i + 1]
         print(f"   {lab}: wave-iters {w:>12d}  lane-iters {a:>12d}  occupancy {a / (64.0 * max(w, 1)):.3f}  per-ray lane-iters {a / st['n_rays']:.2f}")
+    print(f"   tiny-dividend block of [C]: entered in {v[6]} of {v[0]} wave-iterations ({100.0 * v[6] / max(v[0], 1):.1f} %)")
