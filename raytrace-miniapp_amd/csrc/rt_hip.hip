@@ -1106,6 +1106,39 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
     return RT_OK;
 }
 
+// RayTraceImageCPU.cpp:11-16 on the host: grid point i (rounded to float, as the ray carries it) must fall in
+// deposit cell i of the grid g with spacing d -- what makes "ray column i deposits into pixel column i" true
+static bool grid_points_in_own_cells(const double *g, int n, double d)
+{
+    for (int i = 0; i < n; i++) {
+        const double v = (double) (float) g[i];
+        if (v < g[0] - 0.5 * d || v > g[n - 1] + 0.5 * d)
+            return false;
+        const double t = v - 0.5 * d;
+        int idx        = 0;
+        if (t < g[0])
+            idx = 0;
+        else if (t > g[n - 1])
+            idx = n;
+        else {
+            int lo = 0, hi = n - 1;
+            if (n == 1)
+                hi = 1;
+            while (n > 1 && hi - lo != 1) {
+                int mid = (hi + lo) / 2;
+                if (g[mid] >= t)
+                    hi = mid;
+                else
+                    lo = mid;
+            }
+            idx = hi;
+        }
+        if (idx != i)
+            return false;
+    }
+    return true;
+}
+
 int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const double *gy, int ngy,
                              const double *ga, int nga, const double *gb, int ngb, int64_t first,
                              int64_t stride, int64_t count)
@@ -1184,38 +1217,7 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
         }
         return true;
     };
-    // RayTraceImageCPU.cpp:11-16 on the host: grid point i (rounded to float, as the ray
-    // carries it) must fall in deposit cell i
-    auto own_cell = [](const std::vector<double> &g, double d) {
-        const int n = (int) g.size();
-        for (int i = 0; i < n; i++) {
-            const double v = (double) (float) g[(size_t) i];
-            if (v < g[0] - 0.5 * d || v > g[(size_t) n - 1] + 0.5 * d)
-                return false;
-            const double t = v - 0.5 * d;
-            int idx        = 0;
-            if (t < g[0])
-                idx = 0;
-            else if (t > g[(size_t) n - 1])
-                idx = n;
-            else {
-                int lo = 0, hi = n - 1;
-                if (n == 1)
-                    hi = 1;
-                while (n > 1 && hi - lo != 1) {
-                    int mid = (hi + lo) / 2;
-                    if (g[(size_t) mid] >= t)
-                        hi = mid;
-                    else
-                        lo = mid;
-                }
-                idx = hi;
-            }
-            if (idx != i)
-                return false;
-        }
-        return true;
-    };
+    auto own_cell = [](const std::vector<double> &g, double d) { return grid_points_in_own_cells(g.data(), (int) g.size(), d); };
     p->P.exclusive = (p->P.method == 1 && nga == 1 && ngb == 1 && first == 0 && stride == 1 && count == total &&
                       same(p->beam_x, gx, ngx) && same(p->beam_y, gy, ngy) && same(p->beam_a, ga, nga) &&
                       same(p->beam_b, gb, ngb) && own_cell(p->beam_x, p->P.beam.dx) &&
@@ -1704,6 +1706,7 @@ struct RcclApi {
     void *handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort     = nullptr;
     decltype(&ncclGroupStart) GroupStart   = nullptr;
     decltype(&ncclGroupEnd) GroupEnd       = nullptr;
     decltype(&ncclSend) Send               = nullptr;
@@ -1733,6 +1736,7 @@ RcclApi *rccl_api()
         api.error = std::string("librccl.so lacks ") + name;
         RCCL_SYM(CommInitAll, "ncclCommInitAll")
         RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        RCCL_SYM(CommAbort, "ncclCommAbort")
         RCCL_SYM(GroupStart, "ncclGroupStart")
         RCCL_SYM(GroupEnd, "ncclGroupEnd")
         RCCL_SYM(Send, "ncclSend")
@@ -1747,6 +1751,7 @@ RcclApi *rccl_api()
 // one communicator over devices 0 .. ndev-1, kept across calls (creating it costs ~0.1-1 s)
 std::mutex g_multi_mutex; // one multi-device call at a time per process
 std::vector<ncclComm_t> g_comms;
+std::atomic<bool> g_comms_aborted(false); // multi_abort_all() has released them
 thread_local int g_multi_mode = 0;
 
 int multi_comms(int ndev, std::string &err)
@@ -1755,6 +1760,10 @@ int multi_comms(int ndev, std::string &err)
     if (!R->error.empty()) {
         err = R->error;
         return RT_ERR_NO_DEVICE;
+    }
+    if (g_comms_aborted.load()) { // the last call aborted them (multi_abort_all): already released
+        g_comms.clear();
+        g_comms_aborted.store(false);
     }
     if ((int) g_comms.size() == ndev)
         return RT_OK;
@@ -1771,6 +1780,21 @@ int multi_comms(int ndev, std::string &err)
         return RT_ERR_HIP;
     }
     return RT_OK;
+}
+
+// A worker whose part of the collective failed after the rendezvous (an RCCL error, a faulted queue, a peer that
+// never showed up within the time limit) aborts EVERY communicator: ncclCommAbort ends the kernels of a pending
+// collective, so the peers' queues drain and their workers come back instead of waiting for a partner that will
+// never arrive.  The communicators are gone afterwards; the next call builds new ones.
+void multi_abort_all()
+{
+    bool expected = false;
+    if (!g_comms_aborted.compare_exchange_strong(expected, true))
+        return; // once
+    RcclApi *R = rccl_api();
+    for (auto c : g_comms)
+        if (c)
+            (void) R->CommAbort(c);
 }
 
 // all workers arrive, or nobody passes: keeps a failed worker from leaving the others in a collective
@@ -1881,6 +1905,8 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
     if (loopback > 0)
         ndev = loopback;
     auto dev_of = [&](int d) { return loopback > 0 ? 0 : d; };
+    const int inject_fail      = getenv("RT_HIP_MULTI_INJECT_FAIL") ? atoi(getenv("RT_HIP_MULTI_INJECT_FAIL")) : -1;
+    const unsigned timeout_ms  = env_unsigned("RT_HIP_MULTI_TIMEOUT_MS", 120000, 1, 3600000);
     const auto t_begin = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> serial(g_multi_mutex);
     RcclApi *R = nullptr;
@@ -1910,7 +1936,11 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
     // column it starts in (SURVEY.md 8(c) i; the frequency kernel computes the deposit cell per ray anyway)
     const bool tiles = method == 1 && !seed && is_grid && axis_is(G.g[0], beam->x, beam->nx) &&
                        axis_is(G.g[1], beam->y, beam->ny) && axis_is(G.g[2], beam->a, beam->na) &&
-                       axis_is(G.g[3], beam->b, beam->nb) && !getenv("RT_HIP_MULTI_NO_TILES");
+                       axis_is(G.g[3], beam->b, beam->nb) && !getenv("RT_HIP_MULTI_NO_TILES") &&
+                       // ... and column i of the rays deposits into pixel column i of the FULL grid (a tile plan
+                       // runs the deposit index on its own sub-grid with the original dx): the same host check
+                       // that allows the exclusive mode; a beam that fails it takes the chunk mode
+                       grid_points_in_own_cells(beam->x, beam->nx, beam->dx) && grid_points_in_own_cells(beam->y, beam->ny, beam->dy);
     g_multi_mode = tiles ? 1 : 2;
 
     const int nx = beam->nx, ny = beam->ny, K = beam->nv;
@@ -2014,7 +2044,9 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
         if (loopback > 0) {
             // rehearsal: every worker copies its part into the receive layout, worker 0 assembles
             const bool all_ok = meet.arrive(w.rc == RT_OK);
-            if (all_ok) {
+            if (all_ok && inject_fail == d)
+                fail(RT_ERR_HIP, "injected failure after the rendezvous (RT_HIP_MULTI_INJECT_FAIL)");
+            if (all_ok && w.rc == RT_OK) {
                 hip_ok(hipMemcpyAsync(recv0 + (size_t) d * stride, buf, stride * sizeof(double), hipMemcpyDeviceToDevice, q),
                        "loopback copy");
                 hip_ok(hipStreamSynchronize(q), "hipStreamSynchronize");
@@ -2038,7 +2070,12 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
             }
         } else if (meet.arrive(w.rc == RT_OK)) {
             ncclResult_t r = ncclSuccess;
-            if (tiles) {
+            // (test hook: RT_HIP_MULTI_INJECT_FAIL=d makes worker d fail here, after the rendezvous, without
+            // entering the collective -- what a faulted queue or a failed enqueue looks like to its peers)
+            const bool injected = inject_fail == d;
+            if (injected) {
+                fail(RT_ERR_HIP, "injected failure after the rendezvous (RT_HIP_MULTI_INJECT_FAIL)");
+            } else if (tiles) {
                 r = R->GroupStart();
                 if (r == ncclSuccess)
                     r = R->Send(buf, stride, ncclDouble, 0, g_comms[(size_t) d], q);
@@ -2059,8 +2096,38 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
             }
             if (r != ncclSuccess)
                 fail(RT_ERR_HIP, std::string("RCCL: ") + R->GetErrorString(r));
-            if (w.rc == RT_OK)
-                hip_ok(hipStreamSynchronize(q), "hipStreamSynchronize");
+            if (w.rc != RT_OK) {
+                multi_abort_all(); // the peers must not wait for this worker's part
+            } else {
+                // wait for the collective -- but not for ever: a peer that failed aborts the communicators
+                // (its own abort ends this queue's kernels), and a peer that never arrives is given
+                // RT_HIP_MULTI_TIMEOUT_MS (default 120 s) before this worker aborts them itself
+                const auto t_wait = std::chrono::steady_clock::now();
+                for (;;) {
+                    const hipError_t e = hipStreamQuery(q);
+                    if (e == hipSuccess)
+                        break;
+                    if (e != hipErrorNotReady) {
+                        hip_ok(e, "collective");
+                        multi_abort_all();
+                        break;
+                    }
+                    if (g_comms_aborted.load()) {
+                        fail(RT_ERR_HIP, "collective aborted: another device failed");
+                        break;
+                    }
+                    const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
+                    if (waited > (double) timeout_ms) {
+                        fail(RT_ERR_HIP, "collective timed out after " + std::to_string(timeout_ms) + " ms");
+                        multi_abort_all();
+                        break;
+                    }
+                    if (waited > 0.2) // spin for the first 200 us (the stand-in's gather takes ~50), then yield
+                        std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if (w.rc == RT_OK && g_comms_aborted.load())
+                    fail(RT_ERR_HIP, "collective aborted: another device failed");
+            }
             if (w.rc == RT_OK && d == 0) {
                 hip_ok(hipMemcpy(image, out0, n_img * sizeof(double), hipMemcpyDeviceToHost), "download image");
                 hip_ok(hipMemcpy(I_ang, out0 + n_img, n_ang * sizeof(double), hipMemcpyDeviceToHost), "download I_ang");
@@ -2084,11 +2151,13 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
         th.emplace_back(work, d);
     for (auto &t : th) // join EVERY worker, then report the first error
         t.join();
-    for (int d = 0; d < ndev; d++)
-        if (W[(size_t) d].rc != RT_OK) {
-            g_last_error = "device " + std::to_string(d) + ": " + W[(size_t) d].error;
-            return W[(size_t) d].rc;
-        }
+    // (a worker that was pulled out of the collective by another one's abort is not the one to quote)
+    for (int pass = 0; pass < 2; pass++)
+        for (int d = 0; d < ndev; d++)
+            if (W[(size_t) d].rc != RT_OK && (pass == 1 || W[(size_t) d].error.rfind("collective aborted", 0) != 0)) {
+                g_last_error = "device " + std::to_string(d) + ": " + W[(size_t) d].error;
+                return W[(size_t) d].rc;
+            }
     unsigned code = 0;
     int nf        = 0;
     rt_stats tot  = {};

@@ -73,6 +73,20 @@ __device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray
 __device__ __attribute__((noinline)) float tan_wide(float x) { return (float) tan((double) x); }
 __device__ __attribute__((noinline)) float atan_wide(float x) { return (float) atan((double) x); }
 
+// The three float kernels below (ktanf_flt32 / tanf_flt32_wide / tanf_flt32_kernel, atanf_flt32_kernel) restate
+// routines of fdlibm as shipped in GNU libc 2.35 (sysdeps/ieee754/flt-32/k_tanf.c, e_rem_pio2f.c, s_atanf.c;
+// float conversions by Ian Lance Taylor, Cygnus Support) -- same coefficients, same evaluation order, because
+// bit-exactness with the reference platform's libm requires it.  Their notice:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+//
 // tanf as the reference's libm computes it.  Helper.h:409-410 calls tanf(1e-3f * a); on
 // the reference platform that is GNU libc 2.35, sysdeps/ieee754/flt-32/{s,k}_tanf.c --
 // the fdlibm float kernel: for |x| < 0.6744 a degree-13 odd polynomial evaluated in float

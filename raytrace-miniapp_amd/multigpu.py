@@ -58,16 +58,21 @@ class Assembler:
         # box whose ranks share one GPU; RCCL takes the device buffers directly)
         self.via_host = via_host and dev.type != "cpu"
         cdev = torch.device("cpu") if self.via_host else dev
+        # the gather's receive buffer (world x (tile | I_ang) on rank dst) is allocated by the first assemble():
+        # a run that leaves its tiles on their GPUs (bench.py --no-assemble, config 5) never pays for it
         self.recv = None
-        if world > 1 and not self.seeded and rank == dst:
-            self.recv = torch.empty((world, self.n_tile_max + self.n_ang), dtype=torch.float64, device=cdev)
+        self._recv_dev = cdev
+        self.last_collective = None  # what the last assemble() ran, for describe()
 
     def describe(self) -> str:
         n = (self.n_tile_max + self.n_ang) * 8
         if self.seeded:
-            return f"reduce(sum, f64) of {n} B (image | I_ang) to rank {self.dst}"
-        return (f"gather of {n} B (pixel-column tile | I_ang) per rank to rank {self.dst}, one interleave copy, "
-                f"one I_ang sum")
+            plan = f"reduce(sum, f64) of {n} B (image | I_ang) to rank {self.dst}"
+        else:
+            plan = (f"gather of {n} B (pixel-column tile | I_ang) per rank to rank {self.dst}, one interleave copy, "
+                    f"one I_ang sum")
+        ran = self.last_collective or "none yet"
+        return f"{plan}; last run: {ran}"
 
     def assemble(self, buffer=None):
         """Returns (image, I_ang) flat tensors on rank dst, (None, None) elsewhere."""
@@ -80,11 +85,16 @@ class Assembler:
             return buf[:self.n_tile], buf[self.n_tile_max:]
         if self.via_host:
             buf = buf.cpu()
+        backend = dist.get_backend(self.group) + (" via host copies" if self.via_host else "")
         if self.seeded:
             dist.reduce(buf, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_collective = f"torch.distributed.reduce(SUM) over {backend}, world {self.world}"
             return (buf[:self.n_tile], buf[self.n_tile_max:]) if self.rank == self.dst else (None, None)
+        if self.rank == self.dst and self.recv is None:
+            self.recv = torch.empty((self.world, self.n_tile_max + self.n_ang), dtype=torch.float64, device=self._recv_dev)
         parts = list(self.recv.unbind(0)) if self.rank == self.dst else None
         dist.gather(buf, gather_list=parts, dst=self.dst, group=self.group)
+        self.last_collective = f"torch.distributed.gather over {backend}, world {self.world}"
         if self.rank != self.dst:
             return None, None
         iang = self.recv[:, self.n_tile_max:].sum(0)

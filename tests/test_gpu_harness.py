@@ -15,10 +15,23 @@ BIN = ROOT / "oracle" / "_ref" / "CreateImageHip"
 pytestmark = pytest.mark.gpu
 
 
+def need(exe: Path):
+    """The binaries of oracle/_ref/ exist only where the reference tree was present at build time
+    (__graft_entry__.build() records that in oracle/ref_build_stamp.json).  Built there but missing here is a
+    FAILURE (the snapshot lost them, and these boundary tests would silently not run); never built is a skip."""
+    if exe.exists():
+        return
+    import json
+    stamp = ROOT / "oracle" / "ref_build_stamp.json"
+    if stamp.exists() and json.loads(stamp.read_text()).get("reference_present"):
+        pytest.fail(f"{exe.relative_to(ROOT)} is missing although build() ran with the reference tree present: the "
+                    "boundary tests cannot run")
+    pytest.skip(f"{exe.relative_to(ROOT)} was not built (no reference tree where build() ran)")
+
+
 @pytest.mark.parametrize("name", ["ASE_small", "seed_small"])
 def test_reference_harness_with_hip_backend(tmp_path, name):
-    if not BIN.exists():
-        pytest.skip("oracle/_ref/CreateImageHip was not built (needs the reference tree)")
+    need(BIN)
     dat = tmp_path / f"{name}.dat"
     dat.write_bytes(lzma.decompress((ROOT / "tests" / "golden" / f"{name}.dat.xz").read_bytes()))
     methods = "cpu,Hip,Hip-MultiGPU" if name == "ASE_small" else "Hip"
@@ -56,8 +69,7 @@ def test_the_real_dispatcher_with_the_hip_arms(tmp_path, name):
     reference's own CreateImage (run_tests, check_ans): `make -C oracle dispatcher` applies the documented
     edits to scratch copies at build time; only the binary travels."""
     exe = ROOT / "oracle" / "_ref" / "CreateImage"
-    if not exe.exists():
-        pytest.skip("oracle/_ref/CreateImage was not built (needs the reference tree)")
+    need(exe)
     dat = tmp_path / f"{name}.dat"
     dat.write_bytes(lzma.decompress((ROOT / "tests" / "golden" / f"{name}.dat.xz").read_bytes()))
     methods = "cpu,Hip,Hip-MultiGPU,auto" if name == "ASE_small" else "Hip,Hip-MultiGPU"
@@ -79,8 +91,7 @@ def test_the_real_dispatcher_aborts_on_failing_rays(tmp_path):
     fail with error -3; the hip arm hands the code back and create_image ends the process with RAY_ERROR."""
     import numpy as np
     exe = ROOT / "oracle" / "_ref" / "CreateImage"
-    if not exe.exists():
-        pytest.skip("oracle/_ref/CreateImage was not built (needs the reference tree)")
+    need(exe)
 
     def poison(p, rt):
         g = p.gain[2]
@@ -102,8 +113,7 @@ def test_the_real_dispatcher_rejects_what_create_image_rejects(tmp_path):
     """The checks in front of the dispatch (src/RayTraceImage.cpp:229-264) run for the hip arm like for any
     other: a non-uniform euv_beam grid is refused before any ray is traced."""
     exe = ROOT / "oracle" / "_ref" / "CreateImage"
-    if not exe.exists():
-        pytest.skip("oracle/_ref/CreateImage was not built (needs the reference tree)")
+    need(exe)
 
     def bend(p, rt):
         import copy
