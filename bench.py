@@ -430,18 +430,7 @@ def main() -> int:
     dt = time.perf_counter() - t0
 
     kms = plan.ring_times()  # (march_ms, freq_ms) of the timed steps, recorded on the launch stream
-    # A second, longer loop of the same step (>= 0.6 s of back-to-back work; never `value`): the timed region of a
-    # 3 ms step is a fraction of a second, too short for an outside GPU-busy sampler to catch.
-    steady = None
-    if not args.no_extras:
-        n_ss = max(args.steps, int(0.6 / max(dt / args.steps, 1e-4)) + 1)
-        torch.cuda.synchronize()
-        s0 = time.perf_counter()
-        for _ in range(n_ss):
-            step()
-        torch.cuda.synchronize()
-        s_dt = time.perf_counter() - s0
-        steady = {"steps": n_ss, "seconds": s_dt, "ms_per_step": s_dt / n_ss * 1e3}
+
     st = plan.fetch(want_image=False)
     stats = st["stats"]
     march_ms = float(np.mean([k[0] for k in kms]))
@@ -454,6 +443,23 @@ def main() -> int:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     dt_max, kernel_ms_max = float(t[0].item()), float(t[1].item())
     steps_all, rays_all = int(cnt[0].item()), int(cnt[1].item())
+    # A second, longer loop of the same step (>= 0.6 s of back-to-back work; never `value`): the timed region of a
+    # 3 ms step is a fraction of a second, too short for an outside GPU-busy sampler to catch.  The number of
+    # steps comes from the all-reduced time, so that every rank issues the same number of collectives.
+    steady = None
+    if not args.no_extras:
+        n_ss = max(args.steps, int(0.6 / max(dt_max / args.steps, 1e-4)) + 1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        s0 = time.perf_counter()
+        for _ in range(n_ss):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        s_dt = time.perf_counter() - s0
+        steady = {"steps": n_ss, "seconds": s_dt, "ms_per_step": s_dt / n_ss * 1e3}
 
     # N > 1, strong scaling: the per-rank shard of the 6.4 M-ray stand-in is under a millisecond of kernels at
     # N = 8, where the tail of the persistent march (one long ray is ~0.2 ms) and the collective weigh most.

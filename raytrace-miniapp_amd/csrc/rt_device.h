@@ -89,6 +89,10 @@ struct DevRays {
     int ngx, ngy, nga, ngb;
     long long first, stride;
     unsigned long long count;
+    // exact division of a ray number below 2^31 by ngb, nga, ngy (in that order) as multiply-high + shift:
+    // x / d = mulhi(x, mul) >> sh with mul = floor(2^(31+s) / d) + 1, s = ceil(log2 d), sh = s - 1 (rt_hip.hip,
+    // magic_u31); d = 1 is marked by mul = 0 (then x / d = x)
+    unsigned div_mul[3], div_sh[3];
 };
 
 // Per-ray march record, one per ray at rec + ridx * rec_stride:

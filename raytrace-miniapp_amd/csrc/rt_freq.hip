@@ -178,6 +178,49 @@ __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, cons
     }
 }
 
+// The same update with the range reduction and the polynomial in float32 -- for sub-segments with |gs w| <= 80, the
+// rule (DevParams::gs_cap scaled by 80/708 says so per tile).  The argument x = gs * w IS a float (Helper.h:549:
+// the product is rounded to float before it is widened), so nothing is lost by reducing it in float:
+//     n = rint(x 256/ln2) by the magic-constant add (|n| < 2^22), r = x - n ln2/256 with the constant split in two
+//     floats (two fma, |error| < 3e-10), rq = r (1 + r/2 + r^2/6) in float (relative 1e-7 of a term below 1.4e-3);
+// S = 2^m 2^(j/256) and everything that carries magnitude stay float64: e^x - 1 = (S - 1) + S rq to 3e-10 of S,
+// against 1e-10 for the all-float64 form and 1.2e-7 for the rounding of rs that both share.  Five float64-rate
+// instructions per update instead of eleven (the kernel is bound by VALU issue, and a float64 instruction
+// costs two to three float32 ones).
+__device__ __forceinline__ void ase_step_f32(double (&Iv)[VEC], const float gs, const double rs, const float (&w)[VEC],
+                                             const double *tab)
+{
+    const float L2E   = 369.32993f;        // 256 / ln 2
+    const float C_HI  = 2.7076062e-3f;     // ln 2 / 256 rounded to float ...
+    const float C_LO  = (float) (0.0027076061740622863 - (double) 2.7076062e-3f); // ... and the rest
+    const float MAGIC = 12582912.0f;       // 1.5 * 2^23: adding it leaves rint(.) in the low mantissa bits
+    float rq[VEC];
+    double T[VEC];
+    unsigned nb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const float x = gs * w[j];
+        const float t = fmaf(x, L2E, MAGIC);
+        nb[j]         = __float_as_uint(t); // 0x4B400000 + n: low byte = table index, bits 8.. = m (mod 2^12 after << 20)
+        const float n = t - MAGIC;
+        float r       = fmaf(-n, C_HI, x);
+        r             = fmaf(-n, C_LO, r);
+        T[j]          = tab[nb[j] & (EXP_TAB - 1)];
+        float q       = fmaf(r, 1.0f / 6.0f, 0.5f);
+        q             = fmaf(r, q, 1.0f);
+        rq[j]         = r * q;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        // exponent field += m: ((0x4B400000 + n) & ~0xff) << 12 = m << 20 modulo 2^32 (0x4B4000 << 20 vanishes)
+        int hi;
+        asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(nb[j] & 0xffffff00u), "v"(__double2hiint(T[j])));
+        const double S   = __hiloint2double(hi, __double2loint(T[j]));
+        const double em1 = fma(S, (double) rq[j], S - 1.0);
+        Iv[j]            = fma(em1, Iv[j] + rs, Iv[j]);
+    }
+}
+
 // gain sums below this magnitude (or NaN) take the CPU's own formula: es/gs would overflow
 // or the float product gs*w would underflow where es*w does not
 #define RT_RS_MIN 1e-30f
@@ -394,6 +437,18 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     // no such sub-segment in the whole tile (the rule): the six updates of a frequency batch run
     // as one straight-line block, so the table reads of one overlap the arithmetic of another
     const bool all_regular = __ballot(irregular) == 0ull;
+    // ... and every |gs w| of the tile stays below 80 (the rule as well): the float32 range reduction (ase_step_f32)
+    bool big = false;
+    if (SF) {
+#pragma unroll
+        for (int s = 0; s < SF; s++)
+            big = big || !(fabsf(gs[s]) <= H.gs_cap * (80.0f / 708.0f));
+    }
+#ifdef RT_FREQ_NO_F32
+    const bool all_small = false;
+#else
+    const bool all_small = all_regular && __ballot(big) == 0ull;
+#endif
     // a NaN among the lineshape values (the CPU's 0 * NaN) is tested per frequency only when the host
     // scan of the tables found one
     const bool gv_nan = (hflags & FQ_GV_NAN) != 0;
@@ -437,7 +492,11 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                 if (SF) {
                     FVec w[SF ? SF : 1];
                     load_rows(w, kb);
-                    if (all_regular) {
+                    if (all_small) {
+#pragma unroll
+                        for (int s = 0; s < SF; s++)
+                            ase_step_f32(Iv, gs[s], rs[s], w[s].v, tab);
+                    } else if (all_regular) {
 #pragma unroll
                         for (int s = 0; s < SF; s++)
                             ase_step(Iv, gs[s], rs[s], w[s].v, tab);

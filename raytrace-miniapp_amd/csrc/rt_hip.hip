@@ -1106,6 +1106,23 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
     return RT_OK;
 }
 
+// x / d for every x < 2^31 as mulhi(x, mul) >> sh (DevRays::div_mul): with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
+// satisfies mul d = 2^(31+s) + e, 0 < e <= d <= 2^s, hence x mul / 2^(31+s) = x / d + x e / (d 2^(31+s)) with the
+// second term below 1 / d: the floor is that of x / d.  mul < 2^32 for d >= 2; d = 1 is flagged by mul = 0.
+static void magic_u31(unsigned d, unsigned &mul, unsigned &sh)
+{
+    if (d <= 1) {
+        mul = 0;
+        sh  = 0;
+        return;
+    }
+    unsigned s = 0;
+    while ((1ull << s) < d)
+        s++;
+    mul = (unsigned) ((1ull << (31 + s)) / d + 1);
+    sh  = s - 1;
+}
+
 // RayTraceImageCPU.cpp:11-16 on the host: grid point i (rounded to float, as the ray carries it) must fall in
 // deposit cell i of the grid g with spacing d -- what makes "ray column i deposits into pixel column i" true
 static bool grid_points_in_own_cells(const double *g, int n, double d)
@@ -1193,6 +1210,11 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     R.stride       = stride;
     R.count        = (unsigned long long) count;
     p->n_rays      = (unsigned long long) count;
+    {
+        const int divisors[3] = { ngb, nga, ngy };
+        for (int t = 0; t < 3; t++)
+            magic_u31((unsigned) divisors[t], R.div_mul[t], R.div_sh[t]);
+    }
     if (p->P.has_seed && p->P.method != 1) {
         HIP_TRY(dev_malloc((void **) &p->seedtab_dev, nn * sizeof(double) + nn));
         unsigned char *flags = reinterpret_cast<unsigned char *>(p->seedtab_dev + nn);

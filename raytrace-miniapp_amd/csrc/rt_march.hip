@@ -31,16 +31,20 @@ enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 }
 
 // grid mode: indices of ray ridx on the four ray grids
 // (RayTraceImage.cpp:300-328: b fastest, then a, y, x)
+__device__ __forceinline__ unsigned div_magic(unsigned x, unsigned mul, unsigned sh)
+{
+    return mul ? __umulhi(x, mul) >> sh : x; // (wave-uniform select)
+}
 __device__ __forceinline__ void grid_index(const DevRays &R, unsigned ridx, unsigned &i, unsigned &j, unsigned &k,
                                            unsigned &m)
 {
-    unsigned ijkm = (unsigned) (R.first + (long long) ridx * R.stride);
-    m             = ijkm % (unsigned) R.ngb;
-    unsigned q    = ijkm / (unsigned) R.ngb;
-    k             = q % (unsigned) R.nga;
-    q /= (unsigned) R.nga;
-    j = q % (unsigned) R.ngy;
-    i = q / (unsigned) R.ngy;
+    const unsigned ijkm = (unsigned) (R.first + (long long) ridx * R.stride); // < 2^31 (rt_hip_plan_set_ray_grid)
+    const unsigned q1   = div_magic(ijkm, R.div_mul[0], R.div_sh[0]);
+    m                   = ijkm - q1 * (unsigned) R.ngb;
+    const unsigned q2   = div_magic(q1, R.div_mul[1], R.div_sh[1]);
+    k                   = q1 - q2 * (unsigned) R.nga;
+    i                   = div_magic(q2, R.div_mul[2], R.div_sh[2]);
+    j                   = q2 - i * (unsigned) R.ngy;
 }
 
 // start ray of flat index ridx: position, and tangent of the launch angles
@@ -515,10 +519,15 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // (the threshold follows the number of lanes that still hold a ray: a fifth of them, at most
         // P.park -- in the tail of a launch, when a wave is down to a few rays, a fixed threshold would make
         // each of them wait for all the others: 1024 rays took 0.34 ms with it, as long as 400 000)
+        // (while the ray counter still has rays the wave holds more than 64 - REFILL of them, a fifth of which is 12:
+        // for P.park <= 12 the threshold is P.park itself, and the adaptive form runs only in the tail of the launch)
         const unsigned long long want_a = __ballot(st == ST_CELL);
-        const int n_live  = WAVE - (int) __popcll(idle2);
-        const int fifth   = (n_live * 13 + 63) >> 6; // ~ n_live / 5, at least 1 for a live lane
-        const int park_at = fifth < (int) P.park ? fifth : (int) P.park;
+        int park_at = (int) P.park;
+        if (!more || (int) P.park > 12 || REFILL > 8) {
+            const int n_live = WAVE - (int) __popcll(idle2);
+            const int fifth  = (n_live * 13 + 63) >> 6; // ~ n_live / 5, at least 1 for a live lane
+            park_at          = fifth < (int) P.park ? fifth : (int) P.park;
+        }
         const bool do_a = (int) __popcll(want_a) >= park_at || (~(idle2 | want_a)) == 0ull;
         if (do_a && st == ST_CELL) {
             bool in_seg        = !escaped & (z < 0.995f * z_stop);

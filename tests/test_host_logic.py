@@ -180,3 +180,29 @@ def test_assembler_single_rank_is_a_view_of_its_buffer(ase_small):
     # tiles of an uneven split: widths differ by at most one column and cover the image
     cols = [mg.tile_columns(b.nx, r, 7) for r in range(7)]
     assert sum(cols) == b.nx and max(cols) - min(cols) <= 1
+
+
+def test_magic_number_division_of_ray_numbers_is_exact():
+    """DevRays::div_mul / div_sh (rt_hip.hip, magic_u31): x // d == (x * mul >> 32) >> sh for every x < 2^31, where
+    mul = floor(2^(31+s) / d) + 1, s = ceil(log2 d), sh = s - 1 -- the rule the march uses to split a ray number
+    into its grid indices (RayTraceImage.cpp:300-328) without an integer division.  The GPU parity tests cover the
+    kernel itself; this pins the arithmetic, including the edge divisors."""
+    import random
+    rnd = random.Random(7)
+
+    def magic(d):
+        s = 0
+        while (1 << s) < d:
+            s += 1
+        return (1 << (31 + s)) // d + 1, s - 1
+
+    divisors = list(range(2, 600)) + [(1 << k) + e for k in range(1, 31) for e in (-1, 0, 1) if (1 << k) + e >= 2]
+    divisors += [rnd.randrange(2, 1 << 31) for _ in range(500)]
+    for d in divisors:
+        mul, sh = magic(d)
+        assert 0 < mul < (1 << 32) and sh >= 0
+        xs = [0, 1, d - 1, d, d + 1, 2 * d - 1, (1 << 31) - 1, (1 << 31) - d, max(0, (1 << 31) - d - 1)]
+        xs += [rnd.randrange(0, 1 << 31) for _ in range(40)]
+        for x in xs:
+            if 0 <= x < (1 << 31):
+                assert ((x * mul) >> 32) >> sh == x // d, (d, x)
