@@ -478,7 +478,10 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     // The frequency loop, instantiated once per deposit mode (exclusive / few runs / row
     // cache / segmented scan) so that each instance keeps only its own deposit state in
     // registers: `deposit(kb, v)` consumes the lane's values of frequencies kb .. kb+VEC-1.
-    auto frequency_loop = [&](auto deposit) {
+    // scale_late: the deposit mode multiplies by `scale` itself, once per summed value instead of once per ray
+    // and frequency (the wave sums of the few-runs mode: sum_r (Iv_r scale) and (sum_r Iv_r) scale differ by
+    // summation-order rounding, which the deposit does not preserve anyway)
+    auto frequency_loop = [&](auto deposit, const bool scale_late = false) {
         // (Requesting the rows of batch kb + 1 early was measured and dropped: a second set of row registers costs
         // the fourth wave per SIMD, 1.34 against 1.30 ms; a request into the same registers right after batch kb
         // has consumed its own, so that the rows travel during the deposit, 1.31 against 1.30 ms and 1.65 against
@@ -600,7 +603,8 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
             for (int j = 0; j < VEC; j++) {
                 iv_min = fmin(iv_min, Iv[j]);
                 angsum += dv2[kb + j] * Iv[j]; // RayTraceImageCPU.cpp:66: (2.0 * dv) * Iv
-                Iv[j] = Iv[j] * H.scale;       // RayTraceImageCPU.cpp:59
+                if (!scale_late)
+                    Iv[j] = Iv[j] * H.scale;   // RayTraceImageCPU.cpp:59
             }
 #ifndef RT_ABL_NODEPOSIT
             if (!safe_check) // the checking pass of a failing run integrates without depositing
@@ -684,11 +688,11 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
 #pragma unroll
                 for (int q = 0; q < MAXQ; q++) {
                     if (pixq[q] >= 0 && k < K)
-                        unsafeAtomicAdd(&H.image[(size_t) pixq[q] * (size_t) K + (size_t) k], win[q * WAVE + lane]);
+                        unsafeAtomicAdd(&H.image[(size_t) pixq[q] * (size_t) K + (size_t) k], win[q * WAVE + lane] * H.scale);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-        });
+        }, true);
     } else if (cached) {
         // LDS atomics serialise on equal addresses (the lanes of one pixel): quads whose four
         // lanes share a pixel add their values with two quad_perm DPP steps and send one atomic

@@ -542,7 +542,7 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     int per_cu          = 0;
     // the integrator's divisions without range bookkeeping where the tables and the step factor allow it
     // (rt_math.h, fdiv_nr; RT_HIP_MARCH_IEEE=1 forces the full IEEE sequences)
-    static const bool force_ieee = getenv("RT_HIP_MARCH_IEEE") != nullptr;
+    const bool force_ieee = getenv("RT_HIP_MARCH_IEEE") != nullptr;
     const bool bounded = p->tables_bounded && p->P.c_h3 >= 1e-8f && !force_ieee;
     using march_fn = void (*)(const rt::DevParams);
     const march_fn kernel = lds_tab ? (bounded ? rt::rt_march_kernel<true, true> : rt::rt_march_kernel<true, false>)

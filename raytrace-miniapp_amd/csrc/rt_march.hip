@@ -366,10 +366,25 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     // ---- tables: copy the march blob to LDS once per work-group ----
     const unsigned char *tab;
     if (LDS_TAB) {
+        // (eight 16-byte loads in flight per lane: the copy of a ~100 KB blob costs one L2 round trip,
+        // not one per 16 KB pass of the work-group)
         const uint4 *src = reinterpret_cast<const uint4 *>(P.blob);
         uint4 *dst       = reinterpret_cast<uint4 *>(lds_raw);
-        for (unsigned i = threadIdx.x; i < P.blob_bytes / 16; i += blockDim.x)
-            dst[i] = src[i];
+        const unsigned n16 = P.blob_bytes / 16, step = blockDim.x;
+        for (unsigned i0 = threadIdx.x; i0 < n16; i0 += 8 * step) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned i = i0 + (unsigned) u * step;
+                v[u]             = src[i < n16 ? i : i0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned i = i0 + (unsigned) u * step;
+                if (i < n16)
+                    dst[i] = v[u];
+            }
+        }
         __syncthreads();
         tab = lds_raw;
     } else {

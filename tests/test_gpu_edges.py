@@ -371,3 +371,36 @@ def test_wide_launch_angles_in_list_mode(hip, oracle, ase_small):
     ref = oracle.image_loop(ase_small, rays)
     assert out["failure_code"] == ref["failure_code"]
     same_outputs_in_a_failing_run(out, ref, tol=1e-5)
+
+
+def test_ieee_division_variant_of_the_march_gives_the_same_records(hip, oracle, ase_small, monkeypatch):
+    """The march has two instances (rt_march.hip, template BOUNDED): short division sequences under table ranges
+    that rt_hip_plan_create verifies, full IEEE divisions otherwise.  RT_HIP_MARCH_IEEE=1 forces the second on
+    the shipped tables: every march record must come out bit-identical to the default run and to the oracle."""
+    ids = np.arange(0, ase_small.n_rays_total, 7, dtype=np.int64)
+    rays = ase_small.build_rays(ids)
+    fast = run_hip(hip, ase_small, rays, probe=True)
+    monkeypatch.setenv("RT_HIP_MARCH_IEEE", "1")
+    slow = run_hip(hip, ase_small, rays, probe=True)
+    monkeypatch.delenv("RT_HIP_MARCH_IEEE")
+    ora = oracle.probe(ase_small, rays, want_Iv=False)
+    same_record(fast["probe"], ora)
+    same_record(slow["probe"], ora)
+    assert np.array_equal(fast["probe"]["ray2"].view(np.uint32), slow["probe"]["ray2"].view(np.uint32))
+    assert rel_l2(fast["image"], slow["image"]) < 1e-14
+
+
+def test_tables_outside_the_verified_ranges_take_the_ieee_march(hip, oracle, ase_small):
+    """A refractive index far from 1 (here n * 6: outside [0.25, 4]) fails the range check of rt_hip_plan_create
+    (tables_bounded), so the run takes the IEEE-division instance of the march by itself; records against the oracle."""
+    p = copy.deepcopy(ase_small)
+    for g in p.gain[1:]:
+        g.n = g.n * 6.0
+    ids = np.arange(0, p.n_rays_total, 23, dtype=np.int64)
+    rays = p.build_rays(ids)
+    out = run_hip(hip, p, rays, probe=True)
+    ora = oracle.probe(p, rays, want_Iv=False)
+    same_record(out["probe"], ora)
+    ref = oracle.image_loop(p, rays)
+    assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    assert rel_l2(out["image"], ref["image"]) < TIGHT
