@@ -30,6 +30,10 @@ namespace rt {
 #endif
 
 constexpr int VEC = 4; // frequencies per lane and pass; rows are padded to a multiple (DevParams::Kp)
+#ifndef RT_FREQ_TILES_PER_FETCH
+#define RT_FREQ_TILES_PER_FETCH 8
+#endif
+constexpr unsigned FREQ_TILES_PER_FETCH = RT_FREQ_TILES_PER_FETCH; // tiles a wave reserves per fetch of the tile counter, at most
 struct alignas(16) FVec { float v[VEC]; };
 
 // ---- float64 building blocks of the frequency pass ---------------------------------
@@ -249,6 +253,56 @@ __device__ __forceinline__ int deposit_index_fast(int n, const double *g, double
     return first_not_below(g, n, t);
 }
 
+// The four deposit cells of a ray at once (RayTraceImageCPU.cpp:11-16 per axis, as deposit_index_fast): the
+// guesses first, then the eight grid values they need in ONE round of loads, then the verification -- a wave
+// that runs the axes one after the other, each behind its own early returns, pays four dependent memory round
+// trips per tile.  g0 / gl = g[0] / g[n-1] come from the argument block (DevBeam::g_first / g_last).
+struct AxisIn {
+    int n;
+    const double *g;
+    double d, inv_d, g0, gl, v;
+};
+__device__ __forceinline__ void deposit_index4(const AxisIn (&A)[4], int (&idx)[4])
+{
+    int u[4];
+    double t[4], lo[4], hi[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        t[a]   = A[a].v - 0.5 * A[a].d;
+        int uu = (int) ((t[a] - A[a].g0) * A[a].inv_d) + 1; // a guess (NaN or out of range: clamped, decided below)
+        const int last = A[a].n - 1;
+        uu   = uu < 1 ? 1 : (uu > last ? last : uu);
+        u[a] = A[a].n >= 2 ? uu : 0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        lo[a] = A[a].g[u[a] > 0 ? u[a] - 1 : 0];
+        hi[a] = A[a].g[u[a]];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const double v = A[a].v, d = A[a].d, g0 = A[a].g0, gl = A[a].gl;
+        int r;
+        if (v < g0 - 0.5 * d || v > gl + 0.5 * d)
+            r = -1;
+        else if (t[a] < g0)
+            r = 0;
+        else if (t[a] > gl || A[a].n < 2)
+            r = A[a].n;
+        else if ((u[a] == 1 || lo[a] < t[a]) && hi[a] >= t[a])
+            r = u[a];
+        else
+            r = -2; // the guess was wrong: bisect (below, behind one branch for the four axes)
+        idx[a] = r;
+    }
+    if (idx[0] == -2 || idx[1] == -2 || idx[2] == -2 || idx[3] == -2) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            if (idx[a] == -2)
+                idx[a] = first_not_below(A[a].g, A[a].n, t[a]);
+    }
+}
+
 // per-wave LDS scratch of the few-runs deposit: [4][XP_ROW] transposition rows (row stride
 // 66 doubles: 16-byte aligned, rows 4 banks apart) + [FREQ_MAXQ][64] window totals
 constexpr int XP_ROW          = 66;
@@ -293,17 +347,45 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
 
     // ---- per-ray preamble: exit ray, seed factor, deposit cells ------------------
     // (everything read through C is loaded here and dead before the frequency loop)
+    // The preamble is a chain of memory round trips, and with ~25 tiles per wave its latency is what the kernel
+    // is made of once the frequency loop is fast (measured: 0.50 of 1.00 ms with the loop compiled out): so every
+    // load that does not depend on another is issued up front -- the whole record (meta + slots) here -- and the
+    // dependent rounds are as few as the mode allows (own-cell rays: none; otherwise one for the deposit cells).
     unsigned fl = 0, steps = 0;
     rt_ray ray  = { 0, 0, 0, 0 };
     RecMeta m   = { 0, 0, 0, 0, 1, 0 };
+    RecSlot raw[SF ? SF : 1]; // slots as stored; those the ray never entered are masked with n_done below
+#pragma unroll
+    for (int s = 0; s < (SF ? SF : 1); s++)
+        raw[s] = RecSlot{ 0.0f, 0.0f, 0 };
     const DevRays R = load_cold(&C->rays);
+    // own-cell rays (FQ_OWN_CELLS): backward method, the rays are the beam's own grid points and the host has
+    // verified that grid point i lands in deposit cell i on all four axes (grid_points_in_own_cells, the CPU's
+    // getIndex on the very float the ray carries): pixel and angle cell ARE the grid indices of the ray
+    const bool own = (hflags & FQ_OWN_CELLS) != 0;
+    const bool need_ray = !own || probe_on; // (a failing own-cell ray loads its start ray when it is reported)
     if (have) {
-        m     = *reinterpret_cast<const RecMeta *>(rec + 12 * (size_t) S);
+        m = *reinterpret_cast<const RecMeta *>(rec + 12 * (size_t) S);
+        if (SF) {
+#pragma unroll
+            for (int s = 0; s < SF; s++)
+                raw[s] = reinterpret_cast<const RecSlot *>(rec)[s];
+        }
+        if (need_ray) {
+            float ta, tb;
+            load_ray(R, ridx, ray, ta, tb, false);
+        }
         fl    = m.flags_steps & REC_FLAG_MASK;
         steps = m.flags_steps >> REC_STEPS_SHIFT;
-        float ta, tb;
-        load_ray(R, ridx, ray, ta, tb, false);
     }
+    auto start_ray = [&]() { // the launch ray, for the failure reports
+        rt_ray r = ray;
+        if (!need_ray) {
+            float ta, tb;
+            load_ray(R, ridx, r, ta, tb, false);
+        }
+        return r;
+    };
     bool err1   = have && (double) (m.sz * m.sz) < 0.01; // Helper.h:515
     rt_ray out  = ray;
     double f0   = 0.0;
@@ -331,23 +413,33 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                 }
             }
         }
-        if (!backward) { // RayTraceImageCPU.cpp:37-49
-            out   = r2;
-            out.a = -out.a;
-            out.b = -out.b;
-            if ((double) out.y < 0.0 && C->beam.y[0] >= 0.0)
-                out.y = -out.y;
-        }
         if (probe_on)
             C->probe.ray2[ridx] = r2;
-        const int i1 = deposit_index_fast(C->beam.nx, C->beam.x, C->beam.dx, C->beam.inv_dx, (double) out.x);
-        const int i2 = deposit_index_fast(C->beam.ny, C->beam.y, C->beam.dy, C->beam.inv_dy, (double) out.y);
-        const int i3 = deposit_index_fast(C->beam.na, C->beam.a, C->beam.da, C->beam.inv_da, (double) out.a);
-        const int i4 = deposit_index_fast(C->beam.nb, C->beam.b, C->beam.db, C->beam.inv_db, (double) out.b);
-        if (i1 >= 0 && i2 >= 0)
-            pix = i1 + i2 * H.nx;
-        if (i3 >= 0 && i4 >= 0)
-            ang = i3 + i4 * C->beam.na;
+        if (own) {
+            unsigned gi, gj, gk, gm;
+            grid_index(R, ridx, gi, gj, gk, gm);
+            pix = (int) (gi + gj * (unsigned) H.nx);
+            ang = (int) (gk + gm * (unsigned) R.nga);
+        } else {
+            if (!backward) { // RayTraceImageCPU.cpp:37-49
+                out   = r2;
+                out.a = -out.a;
+                out.b = -out.b;
+                if ((double) out.y < 0.0 && C->beam.g_first[1] >= 0.0)
+                    out.y = -out.y;
+            }
+            const AxisIn A[4] = {
+                { C->beam.nx, C->beam.x, C->beam.dx, C->beam.inv_dx, C->beam.g_first[0], C->beam.g_last[0], (double) out.x },
+                { C->beam.ny, C->beam.y, C->beam.dy, C->beam.inv_dy, C->beam.g_first[1], C->beam.g_last[1], (double) out.y },
+                { C->beam.na, C->beam.a, C->beam.da, C->beam.inv_da, C->beam.g_first[2], C->beam.g_last[2], (double) out.a },
+                { C->beam.nb, C->beam.b, C->beam.db, C->beam.inv_db, C->beam.g_first[3], C->beam.g_last[3], (double) out.b } };
+            int ix[4];
+            deposit_index4(A, ix);
+            if (ix[0] >= 0 && ix[1] >= 0)
+                pix = ix[0] + ix[1] * H.nx;
+            if (ix[2] >= 0 && ix[3] >= 0)
+                ang = ix[2] + ix[3] * C->beam.na;
+        }
     }
     if (have && probe_on) {
         C->probe.flags[ridx] = fl | (err1 ? F_ERR1 : 0u);
@@ -357,7 +449,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         atomicOr(&H.ctl->failure_code, 1u << 1);
         unsigned slot_f = atomicAdd(&H.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
-            H.ctl->failed[slot_f] = ray;
+            H.ctl->failed[slot_f] = start_ray();
     }
     const bool live = have && !err1 && !(fl & F_SKIP) && !(safe_skip && H.bad[ridx]);
     // exclusive mode: this ray is the only contributor of pixel own_pix and must write its
@@ -418,10 +510,13 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     const bool exact_emis = (hflags & FQ_EXACT_EMIS) != 0;
     bool irregular = false;
     if (SF) {
+        const int n_done = (int) ((m.flags_steps >> REC_NDONE_SHIFT) & REC_NDONE_MASK);
 #pragma unroll
         for (int s = 0; s < SF; s++) {
-            const RecSlot sl = rec_slot(rec, s, SF, m.flags_steps, backward);
-            gs[s]            = sl.g;
+            // (rec_slot's rule on the slots loaded up front: only the first n_done in marching order were written)
+            const bool written = backward ? s >= SF - n_done : s < n_done;
+            const RecSlot sl   = written ? raw[s] : RecSlot{ 0.0f, 0.0f, 0 };
+            gs[s]              = sl.g;
             const float e1   = sl.e;
             off[s]           = (unsigned) sl.c * (unsigned) Kp * 4u;
             // regular: the source-function form (ase_step) takes this sub-segment; not when the gain
@@ -486,7 +581,14 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         // the fourth wave per SIMD, 1.34 against 1.30 ms; a request into the same registers right after batch kb
         // has consumed its own, so that the rows travel during the deposit, 1.31 against 1.30 ms and 1.65 against
         // 1.60 ms seeded -- with four waves per SIMD the latency is covered by the other waves.)
-        for (int kb = 0; kb < K; kb += VEC) {
+#ifdef RT_ABL_NOFREQ // profiling only: the tile preamble alone
+        const int K_loop = K > 1000000 ? K : 0;
+#elif defined(RT_ABL_ONEBATCH) // profiling only: one batch of four frequencies per tile
+        const int K_loop = K < VEC ? K : VEC;
+#else
+        const int K_loop = K;
+#endif
+        for (int kb = 0; kb < K_loop; kb += VEC) {
             double Iv[VEC];
             if (use_emis) {
 #pragma unroll
@@ -755,7 +857,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         atomicOr(&H.ctl->failure_code, bad_neg ? (1u << 2) : (1u << 3));
         unsigned slot_f = atomicAdd(&H.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
-            H.ctl->failed[slot_f] = ray;
+            H.ctl->failed[slot_f] = start_ray();
         if (safe_check)
             H.bad[ridx] = 1;
     }
@@ -793,13 +895,46 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
     }
     __syncthreads();
     const int lane = lane_id();
+    // Tiles are handed out dynamically.  A returning atomic on ONE word is served at ~88 per microsecond chip-wide
+    // (MI355X_MICROARCH.md, "dequeue"): one fetch per 64-ray tile from one counter bounded the whole kernel at
+    // 1.13 ms for the stand-in's 99 750 tiles (measured: 1.22 of 1.26 ms with the frequency loop compiled out) and
+    // made a 12 000-tile launch a pure counter benchmark.  So (i) the tile range is cut into eight shards with a
+    // counter each, on separate cache lines; a wave starts on shard blockIdx.x % 8 (work-groups b and b + 8 share
+    // an XCD: a speed matter only) and moves on to the next shard when its own is empty; (ii) a wave reserves
+    // several tiles per fetch -- guided self-scheduling: (tiles left in the shard) / (2 x waves per shard), at
+    // most FREQ_TILES_PER_FETCH, down to one at the end, where balance matters.
+    const unsigned n_tiles_run = H.tile_end - H.tile_begin;
+    // shard sh owns the tiles sh, sh + 8, sh + 16, ... (interleaved: every shard sees the same mix of cheap and
+    // expensive regions of the image, so the eight run dry together and stealing is an end-game matter)
+    unsigned shard = blockIdx.x & 7u, tried = 0;
+    auto shard_size = [&](unsigned sh) { return (n_tiles_run + 7u - sh) / 8u; };
+    unsigned s_n    = shard_size(shard);
+    unsigned t_next = 0, t_end = 0; // wave-uniform window of reserved tiles (indices inside the shard)
+    const unsigned sh_shift = H.fetch_shift > 3 ? H.fetch_shift - 3 : 0; // log2(2 x waves per shard)
+    auto chunk_of = [&](unsigned left) {
+        const unsigned c = left >> sh_shift;
+        return c < 1u ? 1u : (c > FREQ_TILES_PER_FETCH ? FREQ_TILES_PER_FETCH : c);
+    };
+    unsigned tch = chunk_of(s_n);
     for (;;) {
-        unsigned tile = 0;
-        if (lane == 0)
-            tile = H.tile_begin + atomicAdd(&H.ctl->next_tile_f[H.freq_id], 1u);
-        tile = (unsigned) __builtin_amdgcn_readfirstlane((int) tile);
-        if (tile >= H.tile_end)
-            break;
+        if (t_next == t_end) {
+            unsigned base = 0;
+            if (lane == 0)
+                base = atomicAdd(&H.ctl->next_tile_f[H.freq_id][shard][0], tch);
+            base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+            if (base >= s_n) { // this shard is empty: on to the next one, until all eight have been seen empty
+                if (++tried == 8)
+                    break;
+                shard = (shard + 1) & 7u;
+                s_n   = shard_size(shard);
+                tch   = 1; // a guest takes single tiles
+                continue;
+            }
+            t_next = base;
+            t_end  = s_n - base < tch ? s_n : base + tch;
+            tch    = chunk_of(s_n - t_end);
+        }
+        const unsigned tile = H.tile_begin + (t_next++) * 8u + shard;
         // the cold half of the argument block, addressed inside the kernarg segment; made opaque per tile so
         // that its loads stay in the tile's preamble instead of being hoisted (and kept live) above this loop
         ColdPtr C = (ColdPtr) ((const RT_CONST_AS char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(FreqKArg, cold));
@@ -811,6 +946,7 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
         asm volatile("" : "+s"(hflags), "+v"(lane_t));
         freq_tile<SF, EMIS>(H, hflags, C, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, tile, lane_t);
     }
+#ifndef RT_ABL_NOIANGFLUSH
     if (lds_iang) {
         __syncthreads();
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x) {
@@ -819,6 +955,7 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
                 unsafeAtomicAdd(&H.iang[c], v);
         }
     }
+#endif
 }
 
 } // namespace rt

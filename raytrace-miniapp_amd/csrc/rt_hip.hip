@@ -327,6 +327,12 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         a.hot.tile_begin = P.tile_begin;
         a.hot.tile_end   = P.tile_end;
         a.hot.freq_id    = P.freq_id;
+        {
+            unsigned sh = 0;
+            while ((1ull << sh) < 2ull * grid * 4ull) // 2 x waves (256-thread work-groups)
+                sh++;
+            a.hot.fetch_shift = sh;
+        }
         a.hot.nslot      = nslot;
         a.hot.nx         = P.beam.nx;
         a.hot.ny         = P.beam.ny;
@@ -335,7 +341,8 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
                       (P.safe == 2 ? rt::FQ_SAFE_SKIP : 0u) | (P.exact_emis ? rt::FQ_EXACT_EMIS : 0u) |
                       (P.has_seed ? rt::FQ_HAS_SEED : 0u) | (P.probe_on ? rt::FQ_PROBE : 0u) |
                       (p->gv_has_nan ? rt::FQ_GV_NAN : 0u) | (in_lds ? rt::FQ_IANG_LDS : 0u) |
-                      ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u);
+                      ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u) |
+                      (P.own_cells ? rt::FQ_OWN_CELLS : 0u);
         a.cold.beam  = P.beam;
         a.cold.seed  = P.seed;
         a.cold.rays  = P.rays;
@@ -971,6 +978,14 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     P.beam.inv_dy = 1.0 / beam->dy;
     P.beam.inv_da = 1.0 / beam->da;
     P.beam.inv_db = 1.0 / beam->db;
+    P.beam.g_first[0] = beam->x[0];
+    P.beam.g_first[1] = beam->y[0];
+    P.beam.g_first[2] = beam->a[0];
+    P.beam.g_first[3] = beam->b[0];
+    P.beam.g_last[0]  = beam->x[beam->nx - 1];
+    P.beam.g_last[1]  = beam->y[beam->ny - 1];
+    P.beam.g_last[2]  = beam->a[beam->na - 1];
+    P.beam.g_last[3]  = beam->b[beam->nb - 1];
     if (seed) {
         for (int i = 0; i < 5; i++) {
             P.seed.x[i]   = reinterpret_cast<const double *>(A + off_sx[i]);
@@ -1056,6 +1071,7 @@ static int plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_r
         HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, n_rays * 2 * sizeof(float)));
     }
     p->P.exclusive  = 0;
+    p->P.own_cells  = 0;
     p->P.rays       = {};
     p->P.rays.list  = p->rays_dev;
     p->P.rays.sxy   = p->tan_dev;
@@ -1097,6 +1113,7 @@ int rt_hip_plan_set_rays(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
         }
     }
     p->P.exclusive  = 0;
+    p->P.own_cells  = 0;
     p->P.rays       = {};
     p->P.rays.list  = p->rays_dev;
     p->P.rays.sxy   = p->tan_dev;
@@ -1240,13 +1257,13 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
         return true;
     };
     auto own_cell = [](const std::vector<double> &g, double d) { return grid_points_in_own_cells(g.data(), (int) g.size(), d); };
-    p->P.exclusive = (p->P.method == 1 && nga == 1 && ngb == 1 && first == 0 && stride == 1 && count == total &&
-                      same(p->beam_x, gx, ngx) && same(p->beam_y, gy, ngy) && same(p->beam_a, ga, nga) &&
-                      same(p->beam_b, gb, ngb) && own_cell(p->beam_x, p->P.beam.dx) &&
-                      own_cell(p->beam_y, p->P.beam.dy) && own_cell(p->beam_a, p->P.beam.da) &&
-                      own_cell(p->beam_b, p->P.beam.db))
+    p->P.own_cells = (p->P.method == 1 && same(p->beam_x, gx, ngx) && same(p->beam_y, gy, ngy) && same(p->beam_a, ga, nga) &&
+                      same(p->beam_b, gb, ngb) && own_cell(p->beam_x, p->P.beam.dx) && own_cell(p->beam_y, p->P.beam.dy) &&
+                      own_cell(p->beam_a, p->P.beam.da) && own_cell(p->beam_b, p->P.beam.db) &&
+                      !getenv("RT_HIP_NO_OWN_CELLS"))
                          ? 1u
                          : 0u;
+    p->P.exclusive = (p->P.own_cells && nga == 1 && ngb == 1 && first == 0 && stride == 1 && count == total) ? 1u : 0u;
     return RT_OK;
 }
 

@@ -401,7 +401,14 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     asm volatile("" : "+v"(zs0), "+v"(zs1), "+v"(zs2));
 
     unsigned chunk_next = 0, chunk_end = 0; // wave-uniform window of reserved ray indices
-    bool more           = true;             // wave-uniform: the global counter is not exhausted
+    bool more           = true;             // wave-uniform: the ray counters are not exhausted
+    // The rays of a launch are handed out in chunks of CH by eight counters (shard sh owns the chunks sh, sh + 8,
+    // ...; a wave starts on shard blockIdx.x % 8 and moves on when its own is empty): one counter serves ~88
+    // returning atomics per microsecond chip-wide, which a launch of a few hundred thousand rays comes close to
+    // (rt_freq.hip has the measurements)
+    const unsigned n_launch_rays = n_rays - P.ray_begin;
+    const unsigned n_chunks      = (n_launch_rays + CH - 1) / CH;
+    unsigned shard = blockIdx.x & 7u, shards_seen_empty = 0;
 
     // ---- per-lane state ----
     int st        = ST_IDLE;
@@ -454,16 +461,27 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             bool got = false;
             while (need > 0) {
                 if (chunk_next == chunk_end) {
-                    unsigned base = 0;
+                    unsigned c = 0;
+#ifdef RT_MARCH_ONE_COUNTER // experiment: one counter for all waves
                     if (lane == 0)
-                        base = P.ray_begin + atomicAdd(&P.ctl->next_tile[P.launch_id], CH);
-                    base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
-                    if (base >= n_rays) {
-                        more = false;
-                        break;
+                        c = atomicAdd(&P.ctl->next_tile[P.launch_id][0][0], 1u);
+                    c = (unsigned) __builtin_amdgcn_readfirstlane((int) c);
+                    shards_seen_empty = 7;
+#else
+                    if (lane == 0)
+                        c = atomicAdd(&P.ctl->next_tile[P.launch_id][shard][0], 1u);
+                    c = (unsigned) __builtin_amdgcn_readfirstlane((int) c) * 8u + shard; // chunk number
+#endif
+                    if (c >= n_chunks) { // this shard is empty: the next one, until all eight have been seen empty
+                        if (++shards_seen_empty == 8) {
+                            more = false;
+                            break;
+                        }
+                        shard = (shard + 1) & 7u;
+                        continue;
                     }
-                    chunk_next = base;
-                    chunk_end  = (n_rays - base < CH) ? n_rays : base + CH;
+                    chunk_next = P.ray_begin + c * CH;
+                    chunk_end  = (n_rays - chunk_next < CH) ? n_rays : chunk_next + CH;
                 }
                 int avail = (int) (chunk_end - chunk_next);
                 int take  = avail < need ? avail : need;
@@ -887,12 +905,17 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     {
         unsigned s = wave_sum_u32(tot_steps), e = wave_sum_u32(tot_esc);
         unsigned k = wave_sum_u32(tot_skip), r = wave_sum_u32(tot_rays);
+#ifndef RT_ABL_NOTOTALS
         if (lane == 0) {
             atomicAdd(&P.ctl->cell_steps, (unsigned long long) s);
             atomicAdd(&P.ctl->n_escaped, (unsigned long long) e);
             atomicAdd(&P.ctl->n_skipped, (unsigned long long) k);
             atomicAdd(&P.ctl->n_rays, (unsigned long long) r);
         }
+#else
+        if (lane == 0 && s + e + k + r == 0xffffffffu)
+            atomicAdd(&P.ctl->cell_steps, 1ull);
+#endif
 #ifdef RT_TIMEBLOCKS
         if (lane == 0) {
             for (int i = 0; i < 6; i++)
