@@ -1513,6 +1513,29 @@ int rt_hip_plan_kernel_times(rt_hip_plan *p, float *march_ms, float *freq_ms)
     return RT_OK;
 }
 
+#ifdef RT_WAVETIMES
+// diagnostic build only: wave start / dry / end times of the LAST march launch (100 MHz ticks), then reset
+int rt_hip_debug_wavetimes(unsigned long long *summary8, unsigned long long *end8192, unsigned long long *dry8192)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(summary8, HIP_SYMBOL(rt::g_wt), 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(end8192, HIP_SYMBOL(rt::g_wt_end), 8192 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(dry8192, HIP_SYMBOL(rt::g_wt_dry), 8192 * sizeof(unsigned long long)));
+    unsigned long long init[8] = { ~0ull, 0, ~0ull, 0, ~0ull, 0, 0, 0 };
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wt), init, sizeof(init)));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_INSTRUMENT
+// diagnostic build only: loop iterations per ray of the last march (rays below 2^23)
+int rt_hip_debug_ray_iters(unsigned short *out, unsigned long long n)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_ray_iters), (size_t) n * sizeof(unsigned short)));
+    return RT_OK;
+}
+#endif
 #if defined(RT_INSTRUMENT) || defined(RT_TIMEBLOCKS)
 // diagnostic builds only: read and clear the loop-occupancy / block-clock counters
 int rt_hip_debug_counters(unsigned long long *out8)

@@ -347,6 +347,13 @@ __device__ __forceinline__ int guess_interval(int n, float g0, float inv_h, floa
 // BOUNDED: rt_hip_plan_create has verified the table and step-size ranges under which the integrator's five
 // divisions per step need none of the scaling / fix-up instructions of an IEEE division (rt_math.h, fdiv_nr);
 // otherwise (exotic tables) every division is the full sequence.  Both give the reference's floats.
+#ifdef RT_INSTRUMENT
+__device__ unsigned short g_ray_iters[1u << 23]; // diagnostic: loop iterations each ray occupied its lane for (ray number < 2^23)
+#endif
+#ifdef RT_WAVETIMES // diagnostic: start / counters-dry / end time of every wave of the last launch (100 MHz clock)
+__device__ unsigned long long g_wt[8];
+__device__ unsigned long long g_wt_end[8192], g_wt_dry[8192];
+#endif
 template <bool LDS_TAB, bool BOUNDED>
 __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
 {
@@ -444,8 +451,18 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
 #ifdef RT_TIMEBLOCKS
     unsigned long long tb_acc[6] = { 0, 0, 0, 0, 0, 0 }, tb_last = __builtin_readcyclecounter(), tb_iters = 0;
 #endif
+#ifdef RT_WAVETIMES
+    const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wt_dry = 0;
+#endif
+#ifdef RT_INSTRUMENT
+    unsigned ray_iters = 0;
+#endif
     for (;;) {
         RT_MARK(5); // [C] of the previous iteration
+#ifdef RT_INSTRUMENT
+        ray_iters += st != ST_IDLE ? 1u : 0u;
+#endif
 #ifdef RT_TIMEBLOCKS
         tb_iters++;
 #endif
@@ -475,6 +492,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     if (c >= n_chunks) { // this shard is empty: the next one, until all eight have been seen empty
                         if (++shards_seen_empty == 8) {
                             more = false;
+#ifdef RT_WAVETIMES
+                            wt_dry = __builtin_amdgcn_s_memrealtime();
+#endif
                             break;
                         }
                         shard = (shard + 1) & 7u;
@@ -752,6 +772,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 if (m.px == 1234.5f) // profiling only: the store stays reachable, but never happens
                     *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? sub + 1 : S - sub)) = m;
 #endif
+#ifdef RT_INSTRUMENT
+                if (ridx < (1u << 23))
+                    g_ray_iters[ridx] = (unsigned short) (ray_iters < 65535u ? ray_iters : 65535u);
+                ray_iters = 0;
+#endif
                 tot_steps += steps;
                 tot_esc += escaped ? 1u : 0u;
                 tot_skip += (fl & F_SKIP) ? 1u : 0u;
@@ -901,6 +926,16 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         } // some lane is marching
     }
 
+#ifdef RT_WAVETIMES
+    if (lane == 0) {
+        const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&g_wt[0], wt_start);
+        atomicMax(&g_wt[1], wt_start);
+        const unsigned w = atomicAdd((unsigned *) &g_wt[6], 1u);
+        if (w < 8192)
+            g_wt_end[w] = wt_end, g_wt_dry[w] = wt_dry;
+    }
+#endif
     // ---- launch totals ----
     {
         unsigned s = wave_sum_u32(tot_steps), e = wave_sum_u32(tot_esc);
