@@ -192,12 +192,16 @@ __device__ __forceinline__ void ase_step(double (&Iv)[VEC], const float gs, cons
 // instructions per update instead of eleven (the kernel is bound by VALU issue, and a float64 instruction
 // costs two to three float32 ones).
 __device__ __forceinline__ void ase_step_f32(double (&Iv)[VEC], const float gs, const double rs, const float (&w)[VEC],
-                                             const double *tab)
+                                             const double *tab2)
 {
     const float L2E   = 369.32993f;        // 256 / ln 2
     const float C_HI  = 2.7076062e-3f;     // ln 2 / 256 rounded to float ...
     const float C_LO  = (float) (0.0027076061740622863 - (double) 2.7076062e-3f); // ... and the rest
     const float MAGIC = 12582912.0f;       // 1.5 * 2^23: adding it leaves rint(.) in the low mantissa bits
+    // (the float32 part as v_pk_*_f32 on pairs of frequencies -- two operations per instruction at the issue cost of
+    // one float64 instruction in isolation -- was built and measured: 0.935 against 0.865 ms.  Packed float32 shares
+    // the float64 pipe, which is what this loop is short of; plain float32 instructions of one wave overlap with
+    // float64 instructions of another.)
     float rq[VEC];
     double T[VEC];
     unsigned nb[VEC];
@@ -205,20 +209,21 @@ __device__ __forceinline__ void ase_step_f32(double (&Iv)[VEC], const float gs, 
     for (int j = 0; j < VEC; j++) {
         const float x = gs * w[j];
         const float t = fmaf(x, L2E, MAGIC);
-        nb[j]         = __float_as_uint(t); // 0x4B400000 + n: low byte = table index, bits 8.. = m (mod 2^12 after << 20)
+        nb[j]         = __float_as_uint(t); // 0x4B400000 + n: low byte = table index, bits 8.. = m
         const float n = t - MAGIC;
         float r       = fmaf(-n, C_HI, x);
         r             = fmaf(-n, C_LO, r);
-        T[j]          = tab[nb[j] & (EXP_TAB - 1)];
+        T[j]          = tab2[nb[j] & (EXP_TAB - 1)];
         float q       = fmaf(r, 1.0f / 6.0f, 0.5f);
         q             = fmaf(r, q, 1.0f);
         rq[j]         = r * q;
     }
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-        // exponent field += m: ((0x4B400000 + n) & ~0xff) << 12 = m << 20 modulo 2^32 (0x4B4000 << 20 vanishes)
+        // exponent field += m: the high word of table entry j is stored less j << 12 (exp2_tab2), so that adding
+        // (0x4B400000 + 256 m + j) << 12 = (m << 20) + (j << 12) modulo 2^32 leaves exactly m << 20 on top of it
         int hi;
-        asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(nb[j] & 0xffffff00u), "v"(__double2hiint(T[j])));
+        asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(nb[j]), "v"(__double2hiint(T[j])));
         const double S   = __hiloint2double(hi, __double2loint(T[j]));
         const double em1 = fma(S, (double) rq[j], S - 1.0);
         Iv[j]            = fma(em1, Iv[j] + rs, Iv[j]);
@@ -600,7 +605,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                     if (all_small) {
 #pragma unroll
                         for (int s = 0; s < SF; s++)
-                            ase_step_f32(Iv, gs[s], rs[s], w[s].v, tab);
+                            ase_step_f32(Iv, gs[s], rs[s], w[s].v, tab + EXP_TAB);
                     } else if (all_regular) {
 #pragma unroll
                         for (int s = 0; s < SF; s++)
@@ -875,7 +880,8 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
 {
     // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    __shared__ double exp2_tab[EXP_TAB]; // 2^(j/256), j = 0..255
+    // 2^(j/256), j = 0..255, twice: as it is, and with the high word less j << 12 (ase_step_f32)
+    __shared__ double exp2_tab[2 * EXP_TAB];
     __shared__ __align__(16) double xpose_wg[4 * FREQ_WAVE_XPOSE];
     const FreqHot &H      = A.hot;
     const bool iang_in_lds = (H.flags & FQ_IANG_LDS) != 0;
@@ -887,8 +893,11 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
     double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * ((H.flags & FQ_EXCLUSIVE) ? (size_t) WAVE * XS_ROW : (size_t) nslot * (size_t) H.Kp);
     for (int c = (int) threadIdx.x; c < 4 * nslot * H.Kp; c += (int) blockDim.x)
         cache_wg[c] = 0.0;
-    for (int c = (int) threadIdx.x; c < EXP_TAB; c += (int) blockDim.x)
-        exp2_tab[c] = exp2((double) c * (1.0 / EXP_TAB));
+    for (int c = (int) threadIdx.x; c < EXP_TAB; c += (int) blockDim.x) {
+        const double e        = exp2((double) c * (1.0 / EXP_TAB));
+        exp2_tab[c]           = e;
+        exp2_tab[EXP_TAB + c] = __hiloint2double(__double2hiint(e) - (c << 12), __double2loint(e));
+    }
     if (lds_iang) {
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x)
             lds_iang[c] = 0.0;

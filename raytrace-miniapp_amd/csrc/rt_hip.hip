@@ -274,7 +274,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     // sized so that the RT_FREQ_WAVES work-groups per CU the register budget allows still fit
     // into LDS beside the static scratch (transposition rows, exp table) and the I_ang
     // histogram; fewer than 4 rows is not worth having
-    const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + rt::EXP_TAB * sizeof(double);
+    const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + 2 * rt::EXP_TAB * sizeof(double);
     const size_t lds_fix  = lds_stat + (in_lds ? ang_bytes : 0) + 1024;
     const size_t row_wg   = (size_t) 4 * (size_t) p->P.Kp * sizeof(double); // one cache row in each of the 4 waves
     size_t lds_wg         = (size_t) (160 * 1024) / (EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED);
