@@ -212,6 +212,9 @@ __device__ __forceinline__ void ase_step_f32(double (&Iv)[VEC], const float gs, 
         nb[j]         = __float_as_uint(t); // 0x4B400000 + n: low byte = table index, bits 8.. = m
         const float n = t - MAGIC;
         float r       = fmaf(-n, C_HI, x);
+        // (C_LO is only -7.4e-12, and leaving this correction out saves 2.5 % of the kernel -- but the error it leaves,
+        // 2.7e-9 |x| relative on e^x, is systematic: every gain a little too large.  Measured: the image moved by 1e-8
+        // against the CPU loop.  Kept.)
         r             = fmaf(-n, C_LO, r);
         T[j]          = tab2[nb[j] & (EXP_TAB - 1)];
         float q       = fmaf(r, 1.0f / 6.0f, 0.5f);
