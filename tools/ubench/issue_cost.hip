@@ -70,6 +70,27 @@ BODY(dsread96, "ds_read_b96 v[20:22], %4\n ds_read_b96 v[24:26], %4 offset:16\n"
 BODY(min32, "v_min_f32 %0, %0, %5\n v_min_f32 %1, %1, %6\n")
 BODY(cmp_nop_cnd, "v_cmp_lt_f32 vcc, %0, %5\n s_nop 1\n v_cndmask_b32 %1, %5, %6, vcc\n")
 BODY(readlane, "v_readlane_b32 s10, %0, 3\n v_readlane_b32 s11, %1, 5\n")
+BODY(fma_inl, "v_fma_f32 %0, %0, %5, 1.0\n v_fma_f32 %1, %1, %5, 0.5\n")
+BODY(fmaak, "v_fmaak_f32 %0, %0, %5, 0x3f800000\n v_fmaak_f32 %1, %1, %5, 0x3f000000\n")
+BODY(fmamk, "v_fmamk_f32 %0, %0, 0x3e2aaaab, %5\n v_fmamk_f32 %1, %1, 0x3e2aaaab, %6\n")
+BODY(mul_s, "v_mul_f32 %0, s10, %0\n v_mul_f32 %1, s11, %1\n")
+BODY(add_lit, "v_add_f32 %0, 0x40400000, %0\n v_add_f32 %1, 0x40400000, %1\n")
+BODY(add_inl, "v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 2.0, %1\n")
+BODY(fma_abs_s, "v_fma_f32 %0, -|%0|, %5, s10\n v_fma_f32 %1, -|%1|, %5, s11\n")
+BODY(add64_inl, "v_add_f64 %2, %2, -1.0\n v_add_f64 %3, %3, -1.0\n")
+BODY(fmac64, "v_fmac_f64 %2, %7, %8\n v_fmac_f64 %3, %7, %8\n")
+BODY(fmac32, "v_fmac_f32 %0, %5, %6\n v_fmac_f32 %1, %5, %6\n")
+BODY(fmac32_lit, "v_fmac_f32 %0, 0xbb317218, %5\n v_fmac_f32 %1, 0x2d02e308, %6\n")
+BODY(mix_64_32, "v_fma_f64 %2, %2, %7, %8\n v_fma_f32 %0, %0, %5, %6\n")
+BODY(mix_64_32x2, "v_fma_f64 %2, %2, %7, %8\n v_fma_f32 %0, %0, %5, %6\n v_fma_f32 %1, %1, %5, %6\n")
+BODY(mix_64_pk, "v_fma_f64 %2, %2, %7, %8\n v_pk_fma_f32 %3, %3, %7, %8\n")
+BODY(pkfma_dep, "v_pk_fma_f32 %2, %2, %7, %8\n")
+BODY(fma64_dep, "v_fma_f64 %2, %2, %7, %8\n")
+BODY(mix_64_ds, "v_fma_f64 %2, %2, %7, %8\n ds_read_b64 v[20:21], %4\n")
+BODY(mix_32_ds, "v_fma_f32 %0, %0, %5, %6\n ds_read_b64 v[20:21], %4\n")
+BODY(sdwa, "v_lshlrev_b32_sdwa %4, %9, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_lshlrev_b32_sdwa %4, %9, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n")
+BODY(lshladd, "v_lshl_add_u32 %4, %4, 12, %9\n v_lshl_add_u32 %4, %4, 12, %9\n")
+BODY(mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
 
 struct K { const char *name; void (*fn)(unsigned long long *, int); int per_rep; };
 int main()
@@ -78,7 +99,7 @@ int main()
 #define E(n, c) { #n, k_##n, c }
         E(fma32_dep, 1), E(fma32_ind, 2), E(mul32, 2), E(cndmask, 2), E(cmp32, 2), E(mov, 2), E(min3, 2), E(bfi, 2), E(addu, 2),
         E(mullo, 2), E(rcp32, 2), E(rsq32, 2), E(divscale, 2), E(divfix, 2), E(divfmas, 2), E(fma64, 2), E(mul64, 2), E(add64, 2),
-        E(cvt64_32, 2), E(cvt32_64, 2), E(cmp64, 2), E(pkfma, 2), E(salu, 2), E(mix_fs, 2), E(cnd_e64,2), E(cnd_ind,2), E(cnd_ind64,2), E(snop,2), E(swait,2), E(saveexec,4), E(br_nt,8), E(br_tk,2), E(cmp_cnd,2), E(cmp_e64,2), E(and_b32,2), E(fma_sgpr,2), E(absfma,2), E(dsread,2), E(dsread32,2), E(dsread64,2), E(dsread96,2), E(min32,2), E(cmp_nop_cnd,3), E(readlane,2) };
+        E(cvt64_32, 2), E(cvt32_64, 2), E(cmp64, 2), E(pkfma, 2), E(salu, 2), E(mix_fs, 2), E(cnd_e64,2), E(cnd_ind,2), E(cnd_ind64,2), E(snop,2), E(swait,2), E(saveexec,4), E(br_nt,8), E(br_tk,2), E(cmp_cnd,2), E(cmp_e64,2), E(and_b32,2), E(fma_sgpr,2), E(absfma,2), E(dsread,2), E(dsread32,2), E(dsread64,2), E(dsread96,2), E(min32,2), E(cmp_nop_cnd,3), E(readlane,2), E(fma_inl,2), E(fmaak,2), E(fmamk,2), E(mul_s,2), E(add_lit,2), E(add_inl,2), E(fma_abs_s,2), E(add64_inl,2), E(fmac64,2), E(fmac32,2), E(fmac32_lit,2), E(mix_64_32,2), E(mix_64_32x2,3), E(mix_64_pk,2), E(pkfma_dep,1), E(fma64_dep,1), E(mix_64_ds,2), E(mix_32_ds,2), E(sdwa,2), E(lshladd,2), E(mov_dpp,2) };
     unsigned long long *d;
     hipMalloc(&d, 4096 * 16 * 8);
     const int iters = 500;
