@@ -110,3 +110,64 @@ def test_random_wide_angle_grids_match_oracle(hip, oracle, ase_small, seed_small
     assert out["failure_code"] == ref["failure_code"]
     if ref["failure_code"] == 0 and np.linalg.norm(ref["image"]) > 0:
         assert rel_l2(out["image"], ref["image"]) < (1e-10 if p.seed is not None else 2e-7)
+
+
+def random_grid_case(rng, ase_small, seed_small):
+    """A problem on uniform ray grids of random sizes (what create_image traces): random N, K, dz; shapes that hit the
+    own-cell deposits, the exclusive mode (na = nb = 1), launches with fewer tiles than counter shards."""
+    seeded = rng.random() < 0.4
+    p = copy.copy(seed_small if seeded else ase_small)
+    N = int(rng.integers(2, 5))
+    gains = [p.gain[0]]
+    for i in range(N - 1):
+        g = p.gain[1 + int(rng.integers(0, 2))]
+        gains.append(rt.Gain(g.x, g.y, g.n, g.g0 * np.float32(rng.uniform(0.3, 1.5)), g.E0, g.gv, g.Nv))
+    p.gain = gains
+    if rng.random() < 0.5:
+        p = problem_mod.resample_frequency(p, int(rng.choice([3, 5, 18, 52, 64, 66, 100])))
+    if rng.random() < 0.3:
+        p.beam = copy.copy(p.beam)
+        p.beam.dz = float(p.beam.dz * rng.uniform(0.5, 2.0))
+    shape = rng.choice(["tiny", "flat", "one_angle", "wide"])
+    if shape == "tiny":
+        n = dict(nx=int(rng.integers(1, 4)), ny=int(rng.integers(1, 4)), na=int(rng.integers(1, 4)), nb=int(rng.integers(1, 4)))
+    elif shape == "flat":
+        n = dict(nx=int(rng.integers(2, 30)), ny=int(rng.integers(1, 12)), na=int(rng.integers(1, 9)), nb=int(rng.integers(1, 9)))
+    elif shape == "one_angle":
+        n = dict(nx=int(rng.integers(3, 60)), ny=int(rng.integers(2, 40)), na=1, nb=1)
+    else:
+        n = dict(nx=int(rng.integers(1, 6)), ny=int(rng.integers(1, 6)), na=int(rng.integers(5, 40)), nb=int(rng.integers(5, 30)))
+    p = problem_mod.regrid_seed_beam(p, **n) if seeded else problem_mod.regrid_beam(p, **n)
+    return p, n
+
+
+def check_grid_case(out, ref, seeded):
+    """(ok, worst rel-L2) of a grid-mode result against the oracle's image loop."""
+    ok = out["failure_code"] == ref["failure_code"]
+    if "cell_steps" in out.get("stats", {}):
+        ok = ok and out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+    err = 0.0
+    if ok and ref["failure_code"] == 0:
+        for key in ("image", "I_ang"):
+            if np.linalg.norm(ref[key]) > 0:
+                err = max(err, rel_l2(out[key], ref[key]))
+            else:
+                ok = ok and not np.asarray(out[key]).any()
+        ok = ok and err < (1e-10 if seeded else 2e-7)
+    return ok, err
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_uniform_grids_match_oracle(hip, oracle, ase_small, seed_small, seed):
+    """Grid mode without the probe -- the path create_image takes (tools/fuzz_grid.py runs thousands of these)."""
+    rng = np.random.default_rng(77000 + seed)
+    p, n = random_grid_case(rng, ase_small, seed_small)
+    rays = p.build_rays()
+    ref = oracle.image_loop(p, rays)
+    with hip.Plan(p) as plan:
+        out = plan.set_ray_grid().run().fetch()
+    ok, err = check_grid_case(out, ref, p.seed is not None)
+    assert ok, (n, err, out["failure_code"], ref["failure_code"])
+    if seed % 4 == 0:   # and through the host-pointer entry, which recognises the list as a grid
+        ok, err = check_grid_case(hip.image_loop(p, rays), ref, p.seed is not None)
+        assert ok, ("image_loop", n, err)
