@@ -542,7 +542,9 @@ static int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         // rays on 256 CUs: 0.65 ms with 1024 threads per CU, 0.44 ms with 512; 8 waves per CU is
         // the least that still hides latency).
         const unsigned long long per_cu_rays = p->cu_count ? p->n_rays / (unsigned long long) p->cu_count : 0;
-        bthr = per_cu_rays >= 3ull * 1024 ? 1024u : (per_cu_rays >= 3ull * 768 ? 768u : 512u);
+        // (tools/shard_threads.py on pixel-column shards of the stand-in: 3117 rays per CU 0.461 ms with 768 threads,
+        // 0.472 with 1024; 4156 per CU: equal; 1558 per CU: 0.376 ms with 512, 0.432 with 1024)
+        bthr = per_cu_rays >= 4ull * 1024 ? 1024u : (per_cu_rays >= 2560ull ? 768u : 512u);
     }
     bthr = env_unsigned("RT_HIP_MARCH_THREADS", bthr, 64, lds_tab ? 1024 : 256) / 64 * 64; // occupancy experiments
     const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
