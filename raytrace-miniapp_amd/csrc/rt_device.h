@@ -222,8 +222,16 @@ enum : unsigned {
     FQ_GV_NAN     = 64u,  // some lineshape value is a NaN (found by the host scan): test per frequency
     FQ_IANG_LDS   = 128u, // the I_ang histogram of a work-group lives in LDS
     FQ_NEED_EXIT  = 256u, // the exit angles are needed (forward method, seed, or probe)
-    FQ_OWN_CELLS  = 512u  // DevParams::own_cells: pixel and angle cell of a ray are its grid indices
+    FQ_OWN_CELLS  = 512u, // DevParams::own_cells: pixel and angle cell of a ray are its grid indices
+    FQ_DBG_NOFLUSH = 1024u // profiling only (debug bit 2): the work-groups do not add their I_ang histograms to the result
 };
+// Waves per work-group of the frequency kernel.  One 16-wave work-group per CU (four waves per SIMD, what the
+// registers allow) instead of four 4-wave ones: one I_ang histogram and one pair of exponent tables per CU in LDS,
+// and a quarter of the atomics when the histograms are added to the result at the end of the launch.
+#ifndef RT_FREQ_WG_WAVES
+#define RT_FREQ_WG_WAVES 16
+#endif
+constexpr int FREQ_WG_WAVES = RT_FREQ_WG_WAVES;
 struct FreqHot {
     const float *gv0, *gv1; // SF == 6 (N = 3): lineshape tables of lengths 1 and 2, rows of Kp floats
     const DevGain *gain;    // any N: [N] lineshape pointers, entry 0 unused

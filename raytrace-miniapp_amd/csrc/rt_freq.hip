@@ -317,6 +317,12 @@ constexpr int XP_ROW          = 66;
 constexpr int XS_ROW          = 17; // exclusive mode: staging row of 16 frequencies + 1 (bank spread)
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
+// doubles of dynamic LDS of a work-group (layout: rt_freq_kernel)
+inline size_t freq_lds_doubles(bool iang_in_lds, int n_ang, bool exclusive, int nslot, int Kp, int wg_waves)
+{
+    const size_t per_wave = exclusive ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) Kp;
+    return (size_t) 2 * EXP_TAB + (iang_in_lds ? (size_t) ((n_ang + 1) & ~1) : 0) + (size_t) wg_waves * per_wave;
+}
 
 // constant-address-space views: loads through them are scalar (s_load), whatever else the kernel stores
 #define RT_CONST_AS __attribute__((address_space(4)))
@@ -878,24 +884,38 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     }
 }
 
+#ifdef RT_WAVETIMES
+// diagnostic build: per wave of the last frequency launch {start, tables ready, first tile done, end} (100 MHz ticks)
+__device__ unsigned long long g_ft[6][8192]; // [4]: blockIdx | wave << 16 | XCC_ID << 24 | CU/SE id << 32, [5]: tiles done
+__device__ unsigned g_ft_n;
+#endif
 template <int SF, bool EMIS>
-__global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED) rt_freq_kernel(const FreqKArg A)
+__global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED) rt_freq_kernel(const FreqKArg A)
 {
-    // dynamic LDS: [I_ang histogram, na*nb doubles (if it fits)] [row cache, 4 waves x nslot x K doubles]
+#ifdef RT_WAVETIMES
+    const unsigned long long ft_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ft_first = 0, ft_tiles = 0;
+#endif
+    // LDS of a work-group, all dynamic (launch_freq sizes it with freq_lds_doubles):
+    //   [2^(j/256), j = 0..255, twice: as it is, and with the high word less j << 12 (ase_step_f32)]
+    //   [I_ang histogram, na*nb doubles rounded up to even (if it fits)]
+    //   per wave: [transposition rows + window totals of the few-runs deposit, FREQ_WAVE_XPOSE doubles][row cache [nslot][Kp]],
+    //             or in exclusive mode the store staging rows [64][XS_ROW] alone
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // 2^(j/256), j = 0..255, twice: as it is, and with the high word less j << 12 (ase_step_f32)
-    __shared__ double exp2_tab[2 * EXP_TAB];
-    __shared__ __align__(16) double xpose_wg[4 * FREQ_WAVE_XPOSE];
-    const FreqHot &H      = A.hot;
+    const FreqHot &H       = A.hot;
     const bool iang_in_lds = (H.flags & FQ_IANG_LDS) != 0;
-    const int nslot       = H.nslot;
-    double *lds_iang = iang_in_lds ? reinterpret_cast<double *>(lds_raw) : nullptr;
-    const int n_ang  = H.n_ang;
-    double *cache_wg = reinterpret_cast<double *>(lds_raw) + (iang_in_lds ? n_ang : 0);
-    // per wave: the row cache [nslot][Kp], or in exclusive mode the store staging rows [64][XS_ROW]
-    double *cache    = cache_wg + (size_t) (threadIdx.x >> 6) * ((H.flags & FQ_EXCLUSIVE) ? (size_t) WAVE * XS_ROW : (size_t) nslot * (size_t) H.Kp);
-    for (int c = (int) threadIdx.x; c < 4 * nslot * H.Kp; c += (int) blockDim.x)
-        cache_wg[c] = 0.0;
+    const bool excl        = (H.flags & FQ_EXCLUSIVE) != 0;
+    const int nslot        = H.nslot;
+    const int n_ang        = H.n_ang;
+    double *exp2_tab       = reinterpret_cast<double *>(lds_raw);
+    double *lds_iang       = iang_in_lds ? exp2_tab + 2 * EXP_TAB : nullptr;
+    double *waves_base     = exp2_tab + 2 * EXP_TAB + (iang_in_lds ? ((n_ang + 1) & ~1) : 0);
+    const size_t per_wave  = excl ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) H.Kp;
+    double *mine           = waves_base + (size_t) (threadIdx.x >> 6) * per_wave;
+    double *xpose          = mine; // (not used in exclusive mode)
+    double *cache          = excl ? mine : mine + FREQ_WAVE_XPOSE;
+    for (size_t c = threadIdx.x; c < (size_t) (blockDim.x >> 6) * per_wave; c += blockDim.x)
+        waves_base[c] = 0.0;
     for (int c = (int) threadIdx.x; c < EXP_TAB; c += (int) blockDim.x) {
         const double e        = exp2((double) c * (1.0 / EXP_TAB));
         exp2_tab[c]           = e;
@@ -907,6 +927,9 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
     }
     __syncthreads();
     const int lane = lane_id();
+#ifdef RT_WAVETIMES
+    const unsigned long long ft_ready = __builtin_amdgcn_s_memrealtime();
+#endif
     // Tiles are handed out dynamically.  A returning atomic on ONE word is served at ~88 per microsecond chip-wide
     // (MI355X_MICROARCH.md, "dequeue"): one fetch per 64-ray tile from one counter bounded the whole kernel at
     // 1.13 ms for the stand-in's 99 750 tiles (measured: 1.22 of 1.26 ms with the frequency loop compiled out) and
@@ -956,15 +979,39 @@ __global__ void __launch_bounds__(256, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED
         unsigned hflags = H.flags;
         int lane_t      = lane;
         asm volatile("" : "+s"(hflags), "+v"(lane_t));
-        freq_tile<SF, EMIS>(H, hflags, C, lds_iang, exp2_tab, xpose_wg + (threadIdx.x >> 6) * FREQ_WAVE_XPOSE, cache, tile, lane_t);
+        freq_tile<SF, EMIS>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
+#ifdef RT_WAVETIMES
+        if (!ft_first)
+            ft_first = __builtin_amdgcn_s_memrealtime();
+        ft_tiles++;
+#endif
     }
+#ifdef RT_WAVETIMES
+    const unsigned long long ft_loop_end = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifndef RT_ABL_NOIANGFLUSH
-    if (lds_iang) {
+    if (lds_iang && !(H.flags & FQ_DBG_NOFLUSH)) {
         __syncthreads();
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x) {
             const double v = lds_iang[c];
             if (v != 0.0)
                 unsafeAtomicAdd(&H.iang[c], v);
+        }
+    }
+#endif
+#ifdef RT_WAVETIMES
+    if (lane == 0) {
+        const unsigned w = atomicAdd(&g_ft_n, 1u);
+        if (w < 8192) {
+            g_ft[0][w] = ft_start;
+            g_ft[1][w] = ft_ready;
+            g_ft[2][w] = ft_first ? ft_first : ft_loop_end;
+            g_ft[3][w] = ft_loop_end;
+            unsigned hwid = 0, xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_ft[4][w] = (unsigned long long) blockIdx.x | ((unsigned long long) (threadIdx.x >> 6) << 16) | ((unsigned long long) (xcc & 0xf) << 24) | ((unsigned long long) hwid << 32);
+            g_ft[5][w] = ft_tiles;
         }
     }
 #endif

@@ -270,32 +270,40 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
     const size_t ang_bytes = p->n_iang * sizeof(double);
     // (one global atomic per ray on na*nb addresses serialises badly: the histogram stays in LDS)
     const int in_lds       = ang_bytes <= 32 * 1024;
-    // per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of K doubles,
-    // sized so that the RT_FREQ_WAVES work-groups per CU the register budget allows still fit
-    // into LDS beside the static scratch (transposition rows, exp table) and the I_ang
-    // histogram; fewer than 4 rows is not worth having
-    const size_t lds_stat = (size_t) 4 * rt::FREQ_WAVE_XPOSE * sizeof(double) + 2 * rt::EXP_TAB * sizeof(double);
-    const size_t lds_fix  = lds_stat + (in_lds ? ang_bytes : 0) + 1024;
-    const size_t row_wg   = (size_t) 4 * (size_t) p->P.Kp * sizeof(double); // one cache row in each of the 4 waves
-    size_t lds_wg         = (size_t) (160 * 1024) / (EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED);
-    int nslot             = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / row_wg) : 0;
-    if (!EMIS && nslot < 7) { // seeded tiles hold ~7 pixels: rather one work-group less per CU than no row for them
-        lds_wg = (size_t) (160 * 1024) / (RT_FREQ_WAVES_SEED - 1);
-        nslot  = lds_wg > lds_fix ? (int) ((lds_wg - lds_fix) / row_wg) : 0;
+    // Work-groups of FREQ_WG_WAVES waves; the register budget allows `waves` per SIMD, i.e. wg_per_cu work-groups.
+    // Per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of Kp doubles, as many as fit
+    // into the work-group's share of the 160 KB beside the exponent tables, the I_ang histogram and the per-wave
+    // transposition rows (rt_freq.hip: freq_lds_doubles); fewer than 4 rows is not worth having.
+    const int waves       = EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED;
+    const bool excl       = p->P.exclusive != 0;
+    // (exclusive mode is bound by its stores: 12 waves per CU run 3.6 % faster than 16 -- tools/config5_ab.py)
+    int wg_waves          = (int) env_unsigned("RT_HIP_FREQ_WG_WAVES", excl ? 12u : (unsigned) rt::FREQ_WG_WAVES, 1, (unsigned) rt::FREQ_WG_WAVES);
+    int wg_per_cu         = waves * 4 / wg_waves;
+    wg_per_cu             = wg_per_cu < 1 ? 1 : wg_per_cu;
+    auto lds_of           = [&](int rows) { return rt::freq_lds_doubles(in_lds != 0, (int) p->n_iang, excl, rows, p->P.Kp, wg_waves) * sizeof(double); };
+    auto rows_that_fit    = [&](size_t budget) {
+        int rows = 0;
+        while (rows < 16 && lds_of(rows + 1) + 1024 <= budget)
+            rows++;
+        return rows;
+    };
+    int nslot = 0;
+    if (!excl) { // (exclusive mode: no reduction at all; the space holds the store staging rows instead)
+        nslot = rows_that_fit((size_t) (160 * 1024) / (size_t) wg_per_cu);
+        if (!EMIS && nslot < 7 && wg_per_cu > 1) { // seeded tiles hold ~7 pixels: rather one work-group less per CU than no row for them
+            wg_per_cu--;
+            nslot = rows_that_fit((size_t) (160 * 1024) / (size_t) wg_per_cu);
+        }
+        nslot = nslot < 4 ? 0 : nslot;
     }
-    nslot     = nslot > 16 ? 16 : (nslot < 4 ? 0 : nslot);
-    if (p->P.exclusive) // no reduction at all; the space holds the store staging rows instead
-        nslot = 0;
-    const size_t lds = (in_lds ? ang_bytes : 0) +
-                       (p->P.exclusive ? (size_t) 4 * rt::WAVE * rt::XS_ROW * sizeof(double)
-                                       : (size_t) 4 * (size_t) nslot * (size_t) p->P.Kp * sizeof(double));
+    const size_t lds = lds_of(nslot);
     // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
     // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
     // (surplus work-groups find the tile counter exhausted and leave)
-    int per_cu = (int) ((160 * 1024) / (lds + lds_stat + 512));
-    per_cu     = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    int per_cu = (int) ((160 * 1024) / (lds + 512));
+    per_cu     = per_cu > wg_per_cu ? wg_per_cu : (per_cu < 1 ? 1 : per_cu);
     per_cu = (int) env_unsigned("RT_HIP_FREQ_WGS", (unsigned) per_cu, 1, 16); // tuning override
-    unsigned long long want = ((unsigned long long) (p->P.tile_end - p->P.tile_begin) + 3) / 4;
+    unsigned long long want = ((unsigned long long) (p->P.tile_end - p->P.tile_begin) + (unsigned) wg_waves - 1) / (unsigned) wg_waves;
     unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
     if (cap_blocks && cap > cap_blocks)
         cap = cap_blocks;
@@ -329,7 +337,7 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
         a.hot.freq_id    = P.freq_id;
         {
             unsigned sh = 0;
-            while ((1ull << sh) < 2ull * grid * 4ull) // 2 x waves (256-thread work-groups)
+            while ((1ull << sh) < 2ull * grid * (unsigned long long) wg_waves) // 2 x waves
                 sh++;
             a.hot.fetch_shift = sh;
         }
@@ -342,12 +350,18 @@ static int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
                       (P.has_seed ? rt::FQ_HAS_SEED : 0u) | (P.probe_on ? rt::FQ_PROBE : 0u) |
                       (p->gv_has_nan ? rt::FQ_GV_NAN : 0u) | (in_lds ? rt::FQ_IANG_LDS : 0u) |
                       ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u) |
-                      (P.own_cells ? rt::FQ_OWN_CELLS : 0u);
+                      (P.own_cells ? rt::FQ_OWN_CELLS : 0u) | ((P.debug & 4u) ? rt::FQ_DBG_NOFLUSH : 0u);
         a.cold.beam  = P.beam;
         a.cold.seed  = P.seed;
         a.cold.rays  = P.rays;
         a.cold.probe = P.probe;
-        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3(256), lds, stream, a);
+        // (dynamic LDS above 64 KB has to be allowed per kernel and device; once, the limit is the whole 160 KB)
+        static std::atomic<unsigned long long> lds_allowed{ 0 }; // bit d: done on device d
+        if (lds > 64 * 1024 && p->device < 64 && !(lds_allowed.load() >> p->device & 1ull)) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rt::rt_freq_kernel<SF, EMIS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            lds_allowed.fetch_or(1ull << p->device);
+        }
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3((unsigned) wg_waves * 64), lds, stream, a);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;

@@ -1,4 +1,6 @@
-import importlib, sys, glob
+"""A/B of library builds on the 8-rank shard and on the whole stand-in (round-robin, best of 12).  ORDER=reverse puts
+the product library last -- position matters: see DESIGN.md 4.3."""
+import importlib, os, sys, glob
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")
 be = importlib.import_module("raytrace-miniapp_amd.backend")
@@ -6,6 +8,8 @@ mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
 full = rt.scale_problem(rt.datfile.load('tests/golden/ASE_small.dat.xz'), 16.0)
 for name, p in (("N=8 shard", mg.shard(full, 0, 8)), ("N=1", full)):
     libs = [be.CSRC / "librt_hip.so"] + sorted(glob.glob(str(be.CSRC / "librt_hip_abl_*.so")))
+    if os.environ.get("ORDER") == "reverse":
+        libs = libs[::-1]
     plans = []
     for path in libs:
         plan = be.Plan(p, lib=be.HipLibrary(path)); plan.set_ray_grid(); plans.append(plan)
