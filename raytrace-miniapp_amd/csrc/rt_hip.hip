@@ -1541,6 +1541,16 @@ int rt_hip_debug_wavetimes(unsigned long long *summary8, unsigned long long *end
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wt), init, sizeof(init)));
     return RT_OK;
 }
+// ... and of the LAST frequency launch: times[6][8192] = {start, tables ready, first tile done, last tile done, where, tiles} per wave
+int rt_hip_debug_freqtimes(unsigned long long *times, unsigned *n_waves)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(times, HIP_SYMBOL(rt::g_ft), 6 * 8192 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(n_waves, HIP_SYMBOL(rt::g_ft_n), sizeof(unsigned)));
+    const unsigned zero = 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_ft_n), &zero, sizeof(zero)));
+    return RT_OK;
+}
 #endif
 
 #ifdef RT_INSTRUMENT

@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         atomicMax(&g_wt[1], wt_start);
         const unsigned w = atomicAdd((unsigned *) &g_wt[6], 1u);
         if (w < 8192)
-            g_wt_end[w] = wt_end, g_wt_dry[w] = wt_dry;
+            g_wt_end[w] = wt_end | ((unsigned long long) (threadIdx.x >> 6) << 56), g_wt_dry[w] = wt_dry;
     }
 #endif
     // ---- launch totals ----

@@ -32,11 +32,11 @@ for name, p in (("N=1", full), ("N=8 shard", mg.shard(full, 0, 8))):
           f"tiles after the first, per wave median {np.median(us(t[3] - t[2])):.1f} us")
     where = raw[4]; tiles = raw[5].astype(np.int64)
     blk = (where & np.uint64(0xffff)).astype(np.int64); xcc = ((where >> np.uint64(24)) & np.uint64(0xf)).astype(np.int64)
-    hwid = (where >> np.uint64(32)).astype(np.int64)
+    hwid = (where >> np.uint64(32)).astype(np.int64); wav = ((where >> np.uint64(16)) & np.uint64(0xff)).astype(np.int64)
     cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 0x7; simd = (hwid >> 4) & 0x3
     dur = us(t[3] - t[1]); first = us(t[2] - t[1]); per_tile = dur / np.maximum(tiles, 1)
     print(f"   tiles per wave: min {tiles.min()} median {int(np.median(tiles))} max {tiles.max()}; per-tile time (whole wave): "
           f"min {per_tile.min():.1f} median {np.median(per_tile):.1f} max {per_tile.max():.1f} us")
-    for label, key in (("XCC", xcc), ("block % 8", blk % 8), ("SE", se), ("CU", cu), ("SIMD", simd), ("block / 256", blk // 256)):
+    for label, key in (("XCC", xcc), ("block % 8", blk % 8), ("SE", se), ("CU", cu), ("SIMD", simd), ("block / 256", blk // 256), ("wave in group", wav), ("wave / 4", wav // 4)):
         ks = np.unique(key)
         print(f"   by {label}: " + "  ".join(f"{k}: n {np.sum(key == k)} tile {np.median(per_tile[key == k]):.1f} end {np.median(us(t[3] - t0)[key == k]):.0f}" for k in ks[:16]))
