@@ -861,6 +861,9 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
             for (int k = lane; k < K; k += WAVE) {
                 const double v = cache[q * Kp + k];
                 cache[q * Kp + k] = 0.0;
+#ifdef RT_ABL_NOROWFLUSH // profiling only
+                if (v == 1234.5)
+#endif
                 unsafeAtomicAdd(&H.image[(size_t) pq * (size_t) K + (size_t) k], v);
             }
         }
