@@ -404,3 +404,28 @@ def test_tables_outside_the_verified_ranges_take_the_ieee_march(hip, oracle, ase
     ref = oracle.image_loop(p, rays)
     assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
     assert rel_l2(out["image"], ref["image"]) < TIGHT
+
+
+@pytest.mark.parametrize("case", ["wide_angles", "long_rows", "angles_beyond_lds", "seeded_long_rows"])
+def test_lds_layout_extremes_of_the_frequency_kernel(hip, oracle, ase_small, seed_small, case):
+    """The frequency kernel's work-group keeps its tables, the I_ang histogram and every wave's scratch in one
+    dynamic LDS block (rt_freq.hip: freq_lds_doubles); the corners of that layout against the oracle:
+    a 64 x 64 I_ang histogram (the 32 KB that still fit), a frequency axis whose rows leave no room for a row
+    cache, an I_ang too large for LDS (global atomics), and the seeded pass with long rows (segmented scan)."""
+    if case == "wide_angles":
+        p = problem_mod.regrid_beam(ase_small, nx=3, ny=2, na=64, nb=64)
+    elif case == "long_rows":
+        p = problem_mod.regrid_beam(problem_mod.resample_frequency(ase_small, 700), nx=4, ny=3, na=9, nb=7)
+    elif case == "angles_beyond_lds":
+        p = problem_mod.regrid_beam(ase_small, nx=2, ny=2, na=80, nb=70)
+    else:
+        p = problem_mod.regrid_seed_beam(problem_mod.resample_frequency(seed_small, 700), nx=6, ny=3, na=20, nb=20)
+    rays = p.build_rays()
+    ref = oracle.image_loop(p, rays, n_threads=8)
+    with hip.Plan(p) as plan:
+        out = plan.set_ray_grid().run().fetch()
+    assert out["failure_code"] == ref["failure_code"] == 0
+    tol = 1e-10 if p.seed is not None else TIGHT
+    assert rel_l2(out["image"], ref["image"]) < tol and rel_l2(out["I_ang"], ref["I_ang"]) < tol
+    lst = run_hip(hip, p, rays)      # the same through the ray list (no own cells, no grid tables)
+    assert rel_l2(lst["image"], ref["image"]) < tol and rel_l2(lst["I_ang"], ref["I_ang"]) < tol
