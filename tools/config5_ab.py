@@ -1,3 +1,5 @@
+"""A/B of library builds on the config-5 shape (n x n pixels, 512 frequencies, one ray per pixel):
+python tools/config5_ab.py [n]"""
 import importlib, sys, glob
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")

@@ -1,3 +1,6 @@
+"""What the end-of-launch I_ang flush of the frequency kernel costs on the 8-rank shard, per plan: the same plan with
+and without the flush (debug bit 2), for every library build present (copies of one build show the placement effect:
+DESIGN.md 6)."""
 import importlib, os, sys, glob
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")

@@ -1,3 +1,5 @@
+"""Seeded deposit: distinct image pixels per 64-ray tile and per 2 ... 16 consecutive tiles of seed_small (how much a
+row cache kept across tiles could save)."""
 import importlib, sys
 sys.path.insert(0, '.')
 import numpy as np
