@@ -263,7 +263,8 @@ int rt_hip_plan_enable_path(rt_hip_plan *plan, int on);
 int rt_hip_plan_fetch_path(rt_hip_plan *plan, float *path, int32_t *err);
 
 /* Profiling aid (no reference counterpart): bit 0 = skip the frequency / deposit kernel, bit 1 = skip
- * the march and run the frequency pass over the records of the previous run of this plan.  0 = normal. */
+ * the march and run the frequency pass over the records of the previous run of this plan, bit 2 = the
+ * frequency kernel keeps its per-work-group I_ang sums to itself (I_ang stays zero).  0 = normal. */
 int rt_hip_plan_set_debug(rt_hip_plan *plan, unsigned bits);
 
 void rt_hip_plan_destroy(rt_hip_plan *plan);

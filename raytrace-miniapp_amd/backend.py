@@ -158,7 +158,7 @@ class Plan:
         return self
 
     def set_debug(self, bits: int) -> "Plan":
-        """Profiling aid: bit 0 skips the frequency kernel, bit 1 skips the march (include/rt_hip.h)."""
+        """Profiling aid: bit 0 skips the frequency kernel, bit 1 skips the march, bit 2 the I_ang flush (include/rt_hip.h)."""
         self.hl.check(self.hl.lib.rt_hip_plan_set_debug(self._h, int(bits)), "rt_hip_plan_set_debug")
         return self
 
