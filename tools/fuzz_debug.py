@@ -1,3 +1,4 @@
+"""Re-run one randomised parity case of tests/test_gpu_fuzz.py by seed and print where it differs from the oracle."""
 import importlib, sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np

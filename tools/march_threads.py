@@ -1,3 +1,4 @@
+"""March work-group size (512 ... 1024 threads) and rays per counter fetch on the whole stand-in."""
 import importlib, os, sys
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")
