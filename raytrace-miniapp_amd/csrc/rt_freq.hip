@@ -30,10 +30,15 @@ namespace rt {
 #endif
 
 constexpr int VEC = 4; // frequencies per lane and pass; rows are padded to a multiple (DevParams::Kp)
-#ifndef RT_FREQ_TILES_PER_FETCH
-#define RT_FREQ_TILES_PER_FETCH 8
+// tiles a wave reserves per fetch of the tile counter, at most (see rt_freq_kernel).  With eight counters a fetch per
+// tile is affordable, and for the emission instance it is what measures best (tools/ablate_shard.py with SHARDS=...:
+// stand-in halves 0.47 against 0.52 ms, quarters 0.278 / 0.282, whole 0.865 / 0.868; config 5 at 2048^2 6.64 / 6.89 ms);
+// the gain-only instance keeps the guided chunks (seed_small 1.212 against 1.228 ms)
+#ifdef RT_FREQ_TILES_PER_FETCH
+constexpr unsigned FREQ_TILES_PER_FETCH_EMIS = RT_FREQ_TILES_PER_FETCH, FREQ_TILES_PER_FETCH_GAIN = RT_FREQ_TILES_PER_FETCH;
+#else
+constexpr unsigned FREQ_TILES_PER_FETCH_EMIS = 1, FREQ_TILES_PER_FETCH_GAIN = 8;
 #endif
-constexpr unsigned FREQ_TILES_PER_FETCH = RT_FREQ_TILES_PER_FETCH; // tiles a wave reserves per fetch of the tile counter, at most
 struct alignas(16) FVec { float v[VEC]; };
 
 // ---- float64 building blocks of the frequency pass ---------------------------------
@@ -939,8 +944,8 @@ __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_
     // made a 12 000-tile launch a pure counter benchmark.  So (i) the tile range is cut into eight shards with a
     // counter each, on separate cache lines; a wave starts on shard blockIdx.x % 8 (work-groups b and b + 8 share
     // an XCD: a speed matter only) and moves on to the next shard when its own is empty; (ii) a wave reserves
-    // several tiles per fetch -- guided self-scheduling: (tiles left in the shard) / (2 x waves per shard), at
-    // most FREQ_TILES_PER_FETCH, down to one at the end, where balance matters.
+    // up to FREQ_TILES_PER_FETCH tiles per fetch -- guided self-scheduling: (tiles left in the shard) / (2 x waves per
+    // shard), down to one at the end, where balance matters.
     const unsigned n_tiles_run = H.tile_end - H.tile_begin;
     // shard sh owns the tiles sh, sh + 8, sh + 16, ... (interleaved: every shard sees the same mix of cheap and
     // expensive regions of the image, so the eight run dry together and stealing is an end-game matter)
@@ -949,6 +954,7 @@ __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_
     unsigned s_n    = shard_size(shard);
     unsigned t_next = 0, t_end = 0; // wave-uniform window of reserved tiles (indices inside the shard)
     const unsigned sh_shift = H.fetch_shift > 3 ? H.fetch_shift - 3 : 0; // log2(2 x waves per shard)
+    constexpr unsigned FREQ_TILES_PER_FETCH = EMIS ? FREQ_TILES_PER_FETCH_EMIS : FREQ_TILES_PER_FETCH_GAIN;
     auto chunk_of = [&](unsigned left) {
         const unsigned c = left >> sh_shift;
         return c < 1u ? 1u : (c > FREQ_TILES_PER_FETCH ? FREQ_TILES_PER_FETCH : c);

@@ -6,7 +6,10 @@ rt = importlib.import_module("raytrace-miniapp_amd")
 be = importlib.import_module("raytrace-miniapp_amd.backend")
 mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
 full = rt.scale_problem(rt.datfile.load('tests/golden/ASE_small.dat.xz'), 16.0)
-for name, p in (("N=8 shard", mg.shard(full, 0, 8)), ("N=1", full)):
+cases = [("N=8 shard", mg.shard(full, 0, 8)), ("N=1", full)]
+if os.environ.get("SHARDS"):
+    cases = [(f"N={w} shard", mg.shard(full, 0, int(w)) if int(w) > 1 else full) for w in os.environ["SHARDS"].split(",")]
+for name, p in cases:
     libs = [be.CSRC / "librt_hip.so"] + sorted(glob.glob(str(be.CSRC / "librt_hip_abl_*.so")))
     if os.environ.get("ORDER") == "reverse":
         libs = libs[::-1]
