@@ -6,10 +6,11 @@ rt = importlib.import_module("raytrace-miniapp_amd")
 be = importlib.import_module("raytrace-miniapp_amd.backend")
 mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
 full = rt.scale_problem(rt.datfile.load('tests/golden/ASE_small.dat.xz'), 16.0)
-for world in (8, 6, 16):
-    p = mg.shard(full, 0, world)
-    for thr in (512, 640, 768, 1024):
-        for chunk in (32, 48, 64, 80, 96):
+import os as _os
+for world in [int(w) for w in _os.environ.get('SHARDS', '8,6,16').split(',')]:
+    p = mg.shard(full, 0, world) if world > 1 else full
+    for thr in [int(t) for t in _os.environ.get('THREADS', '512,640,768,1024').split(',')]:
+        for chunk in [int(c) for c in _os.environ.get('CHUNKS', '32,48,64,80,96').split(',')]:
             os.environ["RT_HIP_MARCH_THREADS"] = str(thr); os.environ["RT_HIP_MARCH_CHUNK"] = str(chunk)
             with be.Plan(p) as plan:
                 plan.set_ray_grid().set_timing_ring(10)
