@@ -1,3 +1,4 @@
+"""A/B of library builds on a seeded workload four times the size of seed_small (30.7 M rays)."""
 import importlib, sys, glob
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")
