@@ -8,8 +8,12 @@ rt = importlib.import_module("raytrace-miniapp_amd")
 be = importlib.import_module("raytrace-miniapp_amd.backend")
 base = rt.datfile.load('tests/golden/ASE_small.dat.xz')
 p = rt.scale_problem(base, 16.0)
-for thr in sys.argv[1:] or ["768"]:
-    os.environ["RT_HIP_MARCH_THREADS"] = thr
+if os.environ.get('SHARD'):   # e.g. SHARD=8: the rank-0 shard of an 8-rank run (its march has a long idle tail)
+    mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
+    p = mg.shard(p, 0, int(os.environ['SHARD']))
+for thr in sys.argv[1:] or ["default"]:
+    if thr != "default":
+        os.environ["RT_HIP_MARCH_THREADS"] = thr
     full = be.Plan(p); full.set_ray_grid()
     A = be.Plan(p); A.set_ray_grid(); A.set_debug(1)
     B = be.Plan(p); B.set_ray_grid(); B.run(); B.fetch(want_image=False); B.set_debug(2)
