@@ -28,6 +28,8 @@ for seed in range(first, last):
         outs["plan"] = plan.set_ray_grid().run().fetch()
     if seed % 3 == 0:
         outs["image_loop"] = be.image_loop(p, rays)
+    if (seed - first) % 2000 == 1999:
+        print(f"... {seed - first + 1} cases, {bad} mismatches so far", flush=True)
     for how, out in outs.items():
         ok, err = check_grid_case(out, ref, seeded)
         worst[seeded] = max(worst[seeded], err)

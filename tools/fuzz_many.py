@@ -27,6 +27,8 @@ for seed in range(first, last):
         err = float(np.linalg.norm(out["image"] - ref["image"]) / np.linalg.norm(ref["image"]))
         ok = err < (1e-10 if p.seed is not None else 2e-7)
         worst = max(worst, err)
+    if (seed - first) % 1000 == 999:
+        print(f"... {seed - first + 1} cases, {bad} mismatches so far", flush=True)
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, "N", p.N, "K", p.beam.nv, "seeded", p.seed is not None, "rays", len(rays), "err", err)
