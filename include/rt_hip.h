@@ -123,7 +123,7 @@ int rt_hip_selftest(int device, unsigned long long *n_checked, unsigned long lon
  * (src/RayTraceImage.cpp:300-328) is recognised: the rays are then generated on the device
  * (rt_hip_plan_set_ray_grid) while host threads verify the list ray by ray, bit for bit; should the
  * verification fail the result is discarded and the list itself is uploaded and traced.  Lists of
- * 2^32 - 512 rays or more are rejected (RT_ERR_ARG): the kernels index rays with 32 bits.
+ * 2^32 - 4096 rays or more are rejected (RT_ERR_ARG): the kernels index rays with 32 bits.
  * If failure_code comes back non-zero, image and I_ang hold exactly what RayTraceImageCPULoop leaves:
  * the failing rays deposit nothing (RayTraceImageCPU.cpp:29-36) -- the frequency pass is repeated in a
  * checking mode for such a run.

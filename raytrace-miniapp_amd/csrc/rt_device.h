@@ -20,6 +20,8 @@
 
 namespace rt {
 
+constexpr int WAVE = 64; // lanes of a wavefront; a frequency tile is WAVE consecutive rays
+
 struct alignas(16) Node {
     double n;
     float g0;
@@ -91,7 +93,7 @@ struct DevRays {
     long long first, stride;
     unsigned long long count;
     // exact division of a ray number below 2^31 by ngb, nga, ngy (in that order) as multiply-high + shift:
-    // x / d = mulhi(x, mul) >> sh with mul = floor(2^(31+s) / d) + 1, s = ceil(log2 d), sh = s - 1 (rt_hip.hip,
+    // x / d = mulhi(x, mul) >> sh with mul = floor(2^(31+s) / d) + 1, s = ceil(log2 d), sh = s - 1 (rt_raygrid.hip,
     // magic_u31); d = 1 is marked by mul = 0 (then x / d = x)
     unsigned div_mul[3], div_sh[3];
 };

@@ -1,0 +1,400 @@
+// rt_launch.hip -- the kernels of the path and how a run puts them on a queue.
+//
+// Replaces the launch half of RayTraceImageCudaLoop (src/RayTraceImageCuda.cu:198-203: one thread-per-ray
+// launch): a run is the march kernel (persistent lanes over LDS-resident tables, rt_march.hip) -> one
+// 96-byte record per ray -> the frequency / deposit kernel (rt_freq.hip), back to back on one queue, or the
+// path tracer (rt_path.hip) in place of the frequency kernel.  This is the only translation unit with the
+// kernels of the path in it; the rest of the library reaches them through the functions declared in
+// rt_runtime.h.
+#include "rt_path.hip" // debug path tracer (before rt_freq.hip: no FMA contraction there)
+#include "rt_freq.hip" // kernel B (includes rt_march.hip, kernel A)
+
+#include "rt_runtime.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+using namespace rtr;
+
+namespace {
+
+// Dynamic LDS above 64 KB has to be allowed per kernel and per device, once.
+template <class Kernel> int allow_lds(Kernel kernel, int device, size_t bytes, size_t limit)
+{
+    static std::mutex mu;
+    static std::vector<size_t> allowed; // per device: the size the attribute stands at
+    std::lock_guard<std::mutex> lock(mu);
+    if ((size_t) device >= allowed.size())
+        allowed.resize((size_t) device + 1, 64 * 1024);
+    if (bytes <= allowed[(size_t) device])
+        return RT_OK;
+    const size_t want = limit > bytes ? limit : bytes;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) want));
+    allowed[(size_t) device] = want;
+    return RT_OK;
+}
+
+// frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
+// the shipped inputs; 0 = any N)
+template <int SF, bool EMIS> int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
+{
+    const size_t ang_bytes = p->n_iang * sizeof(double);
+    // (one global atomic per ray on na*nb addresses serialises badly: the histogram stays in LDS)
+    const int in_lds       = ang_bytes <= 32 * 1024;
+    // Work-groups of FREQ_WG_WAVES waves; the register budget allows `waves` per SIMD, i.e. wg_per_cu work-groups.
+    // Per-wave row cache for tiles with several pixel runs (seeded): up to 16 rows of Kp doubles, as many as fit
+    // into the work-group's share of the 160 KB beside the exponent tables, the I_ang histogram and the per-wave
+    // transposition rows (rt_freq.hip: freq_lds_doubles); fewer than 4 rows is not worth having.
+    const int waves       = EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED;
+    const bool excl       = p->P.exclusive != 0;
+    // (exclusive mode is bound by its stores: 12 waves per CU run 3.6 % faster than 16 -- tools/config5_ab.py)
+    int wg_waves          = (int) env_unsigned("RT_HIP_FREQ_WG_WAVES", excl ? 12u : (unsigned) rt::FREQ_WG_WAVES, 1, (unsigned) rt::FREQ_WG_WAVES);
+    int wg_per_cu         = waves * 4 / wg_waves;
+    wg_per_cu             = wg_per_cu < 1 ? 1 : wg_per_cu;
+    auto lds_of           = [&](int rows) { return rt::freq_lds_doubles(in_lds != 0, (int) p->n_iang, excl, rows, p->P.Kp, wg_waves) * sizeof(double); };
+    auto rows_that_fit    = [&](size_t budget) {
+        int rows = 0;
+        while (rows < 16 && lds_of(rows + 1) + 1024 <= budget)
+            rows++;
+        return rows;
+    };
+    int nslot = 0;
+    if (!excl) { // (exclusive mode: no reduction at all; the space holds the store staging rows instead)
+        nslot = rows_that_fit(p->lds_limit / (size_t) wg_per_cu);
+        if (!EMIS && nslot < 7 && wg_per_cu > 1) { // seeded tiles hold ~7 pixels: rather one work-group less per CU than no row for them
+            wg_per_cu--;
+            nslot = rows_that_fit(p->lds_limit / (size_t) wg_per_cu);
+        }
+        nslot = nslot < 4 ? 0 : nslot;
+    }
+    const size_t lds = lds_of(nslot);
+    // persistent grid: as many work-groups per CU as LDS (160 KB) and the wave slots allow; the
+    // occupancy API under-reports large-LDS kernels, and an over-sized grid is harmless here
+    // (surplus work-groups find the tile counter exhausted and leave)
+    int per_cu = (int) (p->lds_limit / (lds + 512));
+    per_cu     = per_cu > wg_per_cu ? wg_per_cu : (per_cu < 1 ? 1 : per_cu);
+    per_cu = (int) env_unsigned("RT_HIP_FREQ_WGS", (unsigned) per_cu, 1, 16); // tuning override
+    unsigned long long want = ((unsigned long long) (p->P.tile_end - p->P.tile_begin) + (unsigned) wg_waves - 1) / (unsigned) wg_waves;
+    unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
+    if (cap_blocks && cap > cap_blocks)
+        cap = cap_blocks;
+    const unsigned grid = (unsigned) (want < cap ? want : cap);
+    if (grid > 0) {
+        // the kernel's own argument block (rt_device.h): hot = what the frequency loop reads, cold = what the
+        // per-ray preamble of a tile reads
+        const rt::DevParams &P = p->P;
+        rt::FreqKArg a;
+        memset(&a, 0, sizeof(a));
+        a.hot.gv0        = p->gv_dev.size() > 1 ? p->gv_dev[1] : nullptr;
+        a.hot.gv1        = p->gv_dev.size() > 2 ? p->gv_dev[2] : nullptr;
+        a.hot.gain       = P.gain;
+        a.hot.rec        = P.rec;
+        a.hot.image      = P.image;
+        a.hot.iang       = P.iang;
+        a.hot.ctl        = P.ctl;
+        a.hot.dv2        = p->dv2_dev;
+        a.hot.seed_fk    = P.has_seed ? P.seed.f[4] : nullptr;
+        a.hot.bad        = P.bad;
+        a.hot.scale      = P.scale;
+        a.hot.gs_cap     = P.gs_cap;
+        a.hot.K          = P.K;
+        a.hot.Kp         = P.Kp;
+        a.hot.L          = P.L;
+        a.hot.method     = P.method;
+        a.hot.rec_stride = P.rec_stride;
+        a.hot.n_rays     = (unsigned) P.rays.count;
+        a.hot.tile_begin = P.tile_begin;
+        a.hot.tile_end   = P.tile_end;
+        a.hot.freq_id    = P.freq_id;
+        {
+            unsigned sh = 0;
+            while ((1ull << sh) < 2ull * grid * (unsigned long long) wg_waves) // 2 x waves
+                sh++;
+            a.hot.fetch_shift = sh;
+        }
+        a.hot.nslot      = nslot;
+        a.hot.nx         = P.beam.nx;
+        a.hot.ny         = P.beam.ny;
+        a.hot.n_ang      = P.beam.na * P.beam.nb;
+        a.hot.flags      = (P.exclusive ? rt::FQ_EXCLUSIVE : 0u) | (P.safe == 1 ? rt::FQ_SAFE_CHECK : 0u) |
+                      (P.safe == 2 ? rt::FQ_SAFE_SKIP : 0u) | (P.exact_emis ? rt::FQ_EXACT_EMIS : 0u) |
+                      (P.has_seed ? rt::FQ_HAS_SEED : 0u) | (P.probe_on ? rt::FQ_PROBE : 0u) |
+                      (p->gv_has_nan ? rt::FQ_GV_NAN : 0u) | (in_lds ? rt::FQ_IANG_LDS : 0u) |
+                      ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u) |
+                      (P.own_cells ? rt::FQ_OWN_CELLS : 0u) | ((P.debug & 4u) ? rt::FQ_DBG_NOFLUSH : 0u);
+        a.cold.beam  = P.beam;
+        a.cold.seed  = P.seed;
+        a.cold.rays  = P.rays;
+        a.cold.probe = P.probe;
+        if (lds > p->lds_limit) {
+            char msg[256];
+            snprintf(msg, sizeof(msg), "frequency kernel: %zu bytes of LDS per work-group (I_ang histogram of %zu cells, %d waves) "
+                     "exceed the device's %zu", lds, p->n_iang, wg_waves, p->lds_limit);
+            return fail_arg(msg);
+        }
+        {
+            const int rc = allow_lds(&rt::rt_freq_kernel<SF, EMIS>, p->device, lds, p->lds_limit);
+            if (rc != RT_OK)
+                return rc;
+        }
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3((unsigned) wg_waves * 64), lds, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+int launch_freq_any(rt_hip_plan *p, hipStream_t stream, unsigned tile_begin = 0, unsigned tile_end = ~0u,
+                           unsigned freq_id = 0)
+{
+    p->P.tile_begin = tile_begin;
+    p->P.tile_end   = tile_end < p->P.n_tiles ? tile_end : p->P.n_tiles;
+    p->P.freq_id    = freq_id;
+    const int S = p->P.L * RT_N_SUB;
+    if (p->P.use_emis)
+        return (S == 6) ? launch_freq<6, true>(p, stream, 0) : launch_freq<0, true>(p, stream, 0);
+    return (S == 6) ? launch_freq<6, false>(p, stream, 0) : launch_freq<0, false>(p, stream, 0);
+}
+
+} // namespace
+
+namespace rtr {
+
+int launch_tan(const rt_ray *rays_dev, unsigned long long n, float *sxy_dev, hipStream_t stream)
+{
+    if (n == 0)
+        return RT_OK;
+    hipLaunchKernelGGL(rt::rt_tan_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, rays_dev, n, sxy_dev);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int launch_seed_tab(const rt::DevSeed &sd, const rt::DevRays &R, size_t n_points, double *sf, unsigned char *sin)
+{
+    hipLaunchKernelGGL(rt::rt_seed_tab_kernel, dim3((unsigned) ((n_points + 255) / 256)), dim3(256), 0, nullptr, sd, R, sf, sin);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int launch_selftest(unsigned long long *counts_dev)
+{
+    hipLaunchKernelGGL(rt::rt_selftest_kernel, dim3(1024), dim3(256), 0, nullptr, counts_dev);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// A run whose frequency pass reported failing rays (error -2 / -3) has deposited them: repeat the pass
+// over the same march records, first integrating without depositing to mark the failing rays, then
+// depositing all others (DevParams::safe).  Leaves image / I_ang as the CPU loop leaves them
+// (RayTraceImageCPU.cpp:29-36) and the failure report as the first pass of the repeat gives it.
+int plan_repeat_checked(rt_hip_plan *p)
+{
+    hipStream_t stream = p->last_stream;
+    if (p->bad_rays < (size_t) p->n_rays || !p->bad_dev) {
+        (void) hipFree(p->bad_dev);
+        p->bad_dev = nullptr;
+        HIP_TRY(dev_malloc((void **) &p->bad_dev, (size_t) p->n_rays + 16));
+        p->bad_rays = (size_t) p->n_rays;
+    }
+    HIP_TRY(hipMemsetAsync(p->bad_dev, 0, (size_t) p->n_rays, stream));
+    HIP_TRY(hipMemsetAsync(&p->ctl->failure_code, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(&p->ctl->n_failed, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(p->ctl->next_tile_f, 0, sizeof(p->ctl->next_tile_f), stream));
+    p->P.bad  = p->bad_dev;
+    p->P.safe = 1;
+    int rc    = launch_freq_any(p, stream);
+    if (rc == RT_OK) {
+        if (!p->P.exclusive)
+            HIP_TRY(hipMemsetAsync(p->last_image, 0, p->n_image * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(p->last_iang, 0, p->n_iang * sizeof(double), stream));
+        HIP_TRY(hipMemsetAsync(p->ctl->next_tile_f, 0, sizeof(p->ctl->next_tile_f), stream));
+        p->P.safe = 2;
+        rc        = launch_freq_any(p, stream);
+    }
+    p->P.safe = 0;
+    p->P.bad  = nullptr;
+    if (rc != RT_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RT_OK;
+}
+
+// Two-kernel path: march (persistent lanes) -> records in HBM -> frequency pass.
+int plan_run_split(rt_hip_plan *p, hipStream_t stream)
+{
+    const size_t need = (size_t) p->n_rays * p->P.rec_stride;
+    if (need > p->rec_bytes || !p->rec) {
+        plan_quiesce(p);
+        pool_free(p->device, p->rec);
+        p->rec = nullptr;
+        HIP_TRY(pool_alloc(p->device, (void **) &p->rec, need ? need : 16));
+        p->rec_bytes = need;
+    }
+    p->P.rec = p->rec;
+    // march: persistent 256-thread work-groups
+    // LDS variant: the whole march blob in LDS, one 1024-thread work-group per CU;
+    // global variant when the blob does not fit (RT_HIP_MARCH=global forces it)
+    const char *force   = getenv("RT_HIP_MARCH");
+    const bool lds_tab  = p->P.blob_bytes + 8 * 1024 <= p->lds_limit && !(force && strcmp(force, "global") == 0);
+    unsigned bthr = lds_tab ? 1024u : 256u;
+    if (lds_tab) {
+        // Few rays per lane leave the persistent lanes waiting for the longest ray of a short
+        // queue: below about three rays per lane, fewer and busier lanes win (ASE_small, 399 000
+        // rays on 256 CUs: 0.65 ms with 1024 threads per CU, 0.44 ms with 512; 8 waves per CU is
+        // the least that still hides latency).
+        const unsigned long long per_cu_rays = p->cu_count ? p->n_rays / (unsigned long long) p->cu_count : 0;
+        // (tools/shard_threads.py on pixel-column shards of the stand-in: 3117 rays per CU 0.461 ms with 768 threads,
+        // 0.472 with 1024; 4156 per CU: equal; 1558 per CU: 0.376 ms with 512, 0.432 with 1024)
+        bthr = per_cu_rays >= 4ull * 1024 ? 1024u : (per_cu_rays >= 2560ull ? 768u : 512u);
+    }
+    bthr = env_unsigned("RT_HIP_MARCH_THREADS", bthr, 64, lds_tab ? 1024 : 256) / 64 * 64; // occupancy experiments
+    const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
+    int per_cu          = 0;
+    // the integrator's divisions without range bookkeeping where the tables and the step factor allow it
+    // (rt_math.h, fdiv_nr; RT_HIP_MARCH_IEEE=1 forces the full IEEE sequences)
+    const bool force_ieee = getenv("RT_HIP_MARCH_IEEE") != nullptr;
+    const bool bounded = p->tables_bounded && p->P.c_h3 >= 1e-8f && !force_ieee;
+    using march_fn = void (*)(const rt::DevParams);
+    const march_fn kernel = lds_tab ? (bounded ? rt::rt_march_kernel<true, true> : rt::rt_march_kernel<true, false>)
+                                    : (bounded ? rt::rt_march_kernel<false, true> : rt::rt_march_kernel<false, false>);
+    if (lds_tab)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) mlds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int) bthr, mlds));
+    if (per_cu < 1)
+        per_cu = 1;
+    unsigned long long want = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
+    unsigned long long cap  = (unsigned long long) p->cu_count * (unsigned) per_cu;
+    const unsigned grid     = (unsigned) (want < cap ? want : cap);
+    // rays reserved per counter fetch: big enough to amortise the atomic, small enough that the last
+    // chunks balance (about 8 chunks per wave), within 64 ... 192 -- swept on the stand-in and on its
+    // strong-scaling shards (tools/shard_sweep2.py): a whole 64-ray refill per fetch is the least that
+    // pays (798 K rays: 0.88 ms at 16, 0.55 at 32, 0.44 at 64, 0.60 at 96), 64 ... 192 is flat at 6.4 M
+    // rays (2.02 ms; 2.66 at 32, 2.05 at 256)
+    unsigned long long ch = grid ? p->n_rays / ((unsigned long long) grid * (bthr / 64) * 8) : 64;
+    ch                    = ch < 64 ? 64 : (ch > 192 ? 192 : ch);
+    p->P.chunk            = (unsigned) ((ch + 15) / 16 * 16);
+    p->P.chunk = env_unsigned("RT_HIP_MARCH_CHUNK", p->P.chunk, 1, 4096); // tuning
+    // lanes that must wait for block [A] of the march before it runs (swept 1 ... 40 on the 6.4 M-ray
+    // stand-in: 2.36 ms at 1, flat optimum 2.12 ms at 8 ... 24, 2.63 ms at 40)
+    p->P.park    = env_unsigned("RT_HIP_MARCH_PARK", 12, 1, 64);
+    p->P.path_on = p->path_on ? 1u : 0u;
+    if (p->path_on) {
+        const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;
+        if (p->path_rays != (size_t) p->n_rays || !p->path_dev) {
+            (void) hipFree(p->path_dev);
+            (void) hipFree(p->path_err);
+            p->path_dev = nullptr;
+            p->path_err = nullptr;
+            HIP_TRY(dev_malloc((void **) &p->path_dev, (size_t) p->n_rays * n2 * 3 * sizeof(float) + 16));
+            HIP_TRY(hipMalloc((void **) &p->path_err, (size_t) p->n_rays * sizeof(int32_t) + 16));
+            p->path_rays = (size_t) p->n_rays;
+        }
+        HIP_TRY(hipMemsetAsync(p->path_dev, 0, (size_t) p->n_rays * n2 * 3 * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(p->path_err, 0, (size_t) p->n_rays * sizeof(int32_t), stream));
+        p->P.path     = p->path_dev;
+        p->P.path_err = p->path_err;
+    }
+    HIP_TRY(hipEventRecord(p->ev0, stream));
+    // A run is one march launch -- or three, when the ray list is still on the host
+    // (rt_hip_image_loop): the list crosses PCIe in slices, each with a synchronous copy (the fast
+    // pageable path, ~35 GB/s; asynchronous copies of pageable memory reach a third of that), and
+    // the march of a slice runs on image_loop's non-blocking queue while the host copies the next
+    // one (16 B/ray: 102 MB, ~3 ms for the 6.4 M-ray case; swept: 3 slices 5.8 ms, 1 slice 6.9, 8 slices 7.3).
+    unsigned n_launch = (p->host_rays && p->n_rays >= (2ull << 20)) ? 3u : 1u;
+    if (p->host_rays)
+        n_launch = env_unsigned("RT_HIP_UPLOAD_SLICES", n_launch, 1, 8); // tuning
+    n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
+    for (unsigned c = 0; c < n_launch && grid > 0 && !(p->P.debug & 2u); c++) {
+        const unsigned long long b = p->n_rays * c / n_launch, e = p->n_rays * (c + 1) / n_launch;
+        if (p->host_rays) {
+            HIP_TRY(hipMemcpy(p->rays_dev + b, p->host_rays + b, (size_t) (e - b) * sizeof(rt_ray), hipMemcpyHostToDevice));
+            // Helper.h:409-410 for every ray of the slice, at full lane occupancy, before its march
+            if (tan_mode(p->device) == 2) { // this host's tanf is not the restated one: its own values
+                std::vector<float> h((size_t) (e - b) * 2);
+                host_tangents(p->host_rays + b, (size_t) (e - b), h.data());
+                HIP_TRY(hipMemcpy(p->tan_dev + 2 * b, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+            } else {
+                hipLaunchKernelGGL(rt::rt_tan_kernel, dim3((unsigned) ((e - b + 255) / 256)), dim3(256), 0, stream,
+                                   p->rays_dev + b, (unsigned long long) (e - b), p->tan_dev + 2 * b);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (n_launch > 1) { // rays reserved per counter fetch, for this slice
+            unsigned long long cs = (e - b) / ((unsigned long long) grid * (bthr / 64) * 8);
+            cs                    = cs < 64 ? 64 : (cs > 192 ? 192 : cs);
+            p->P.chunk            = (unsigned) ((cs + 15) / 16 * 16);
+        }
+        p->P.ray_begin = (unsigned) b;
+        p->P.ray_end   = (unsigned) e;
+        p->P.launch_id = c;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(bthr), mlds, stream, p->P);
+        HIP_TRY(hipGetLastError());
+    }
+    p->host_rays = nullptr; // consumed: the list is on the device now
+    HIP_TRY(hipEventRecord(p->evm, stream));
+    if (p->path_on) {
+        // the tracer replaces the frequency / deposit kernel: no image is produced
+        if (p->n_rays) {
+            hipLaunchKernelGGL(rt::rt_path_kernel, dim3((unsigned) ((p->n_rays + 255) / 256)), dim3(256), 0, stream, p->P);
+            HIP_TRY(hipGetLastError());
+        }
+    } else if (!(p->P.debug & 1u)) {
+        const int rc = launch_freq_any(p, stream);
+        if (rc != RT_OK)
+            return rc;
+    }
+    HIP_TRY(hipEventRecord(p->ev1, stream));
+    return RT_OK;
+}
+
+} // namespace rtr
+
+extern "C" {
+
+#ifdef RT_WAVETIMES
+// diagnostic build only: wave start / dry / end times of the LAST march launch (100 MHz ticks), then reset
+int rt_hip_debug_wavetimes(unsigned long long *summary8, unsigned long long *end8192, unsigned long long *dry8192)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(summary8, HIP_SYMBOL(rt::g_wt), 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(end8192, HIP_SYMBOL(rt::g_wt_end), 8192 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(dry8192, HIP_SYMBOL(rt::g_wt_dry), 8192 * sizeof(unsigned long long)));
+    unsigned long long init[8] = { ~0ull, 0, ~0ull, 0, ~0ull, 0, 0, 0 };
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wt), init, sizeof(init)));
+    return RT_OK;
+}
+// ... and of the LAST frequency launch: times[6][8192] = {start, tables ready, first tile done, last tile done, where, tiles} per wave
+int rt_hip_debug_freqtimes(unsigned long long *times, unsigned *n_waves)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(times, HIP_SYMBOL(rt::g_ft), 6 * 8192 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(n_waves, HIP_SYMBOL(rt::g_ft_n), sizeof(unsigned)));
+    const unsigned zero = 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_ft_n), &zero, sizeof(zero)));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_INSTRUMENT
+// diagnostic build only: loop iterations per ray of the last march (rays below 2^23)
+int rt_hip_debug_ray_iters(unsigned short *out, unsigned long long n)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_ray_iters), (size_t) n * sizeof(unsigned short)));
+    return RT_OK;
+}
+#endif
+#if defined(RT_INSTRUMENT) || defined(RT_TIMEBLOCKS)
+// diagnostic builds only: read and clear the loop-occupancy / block-clock counters
+int rt_hip_debug_counters(unsigned long long *out8)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_inst), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = { 0 };
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_inst), z, sizeof(z)));
+    return RT_OK;
+}
+#endif
+
+} // extern "C"

@@ -9,8 +9,6 @@
 
 namespace rt {
 
-constexpr int WAVE = 64;
-
 #ifdef RT_INSTRUMENT
 // Diagnostic build only (make instrument): lane-occupancy of the three nested
 // march loops.  g_inst[2i] = wave-level iterations, g_inst[2i+1] = active-lane

@@ -1,0 +1,256 @@
+// rt_raygrid.hip -- the ray list of a call, seen from the host: a list that is really a tensor grid
+// (RayTrace::create_image builds every list that way, src/RayTraceImage.cpp:300-328) is recognised and
+// verified so that the device can generate the rays instead of receiving them; the launch tangents of a
+// genuine list (Helper.h:409-410) and the probe that decides who computes them.  Host code only.
+#include "rt_runtime.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace rtr {
+
+// ---- a ray list that is really a tensor grid ---------------------------------------------------
+// RayTrace::create_image builds its list from four 1-D grids, b fastest, then a, y, x
+// (src/RayTraceImage.cpp:300-328), and hands the back-end loop only the list.  The grids are read back
+// from it in O(nx + ny + na + nb) -- the period of each coordinate -- and the whole list is then
+// compared with the grid ray by ray, bit for bit, on host threads.
+bool guess_ray_grid(const rt_ray *rays, size_t n, GridGuess &G)
+{
+    if (n == 0)
+        return false;
+    // period of b: the first later ray whose b equals that of ray 0 (grid values are distinct)
+    size_t nb = 1;
+    while (nb < n && !same_bits(rays[nb].b, rays[0].b))
+        nb++;
+    size_t na = 1;
+    while (na * nb < n && !same_bits(rays[na * nb].a, rays[0].a))
+        na++;
+    size_t ny = 1;
+    while (ny * na * nb < n && !same_bits(rays[ny * na * nb].y, rays[0].y))
+        ny++;
+    const size_t block = nb * na * ny;
+    if (block == 0 || n % block != 0)
+        return false;
+    const size_t nx = n / block;
+    if (nx > 0x7fffffffull || ny > 0x7fffffffull || na > 0x7fffffffull || nb > 0x7fffffffull || n > 0x7fffffffull)
+        return false;
+    G.g[0].resize(nx);
+    G.g[1].resize(ny);
+    G.g[2].resize(na);
+    G.g[3].resize(nb);
+    for (size_t i = 0; i < nx; i++)
+        G.g[0][i] = (double) rays[i * block].x;
+    for (size_t j = 0; j < ny; j++)
+        G.g[1][j] = (double) rays[j * na * nb].y;
+    for (size_t k = 0; k < na; k++)
+        G.g[2][k] = (double) rays[k * nb].a;
+    for (size_t m = 0; m < nb; m++)
+        G.g[3][m] = (double) rays[m].b;
+    return true;
+}
+
+// every ray of the list against the grid, on up to `threads` host threads.  A ray is two 64-bit words,
+// (x, y) and (a, b); a run of nb rays shares the first word and the a half of the second, so the
+// inner loop is two integer compares per ray over a stream the memory system prefetches: ~1 ms for the
+// 102 MB of a 6.4 M-ray list on 16 threads, hidden behind the kernels it runs beside.
+bool verify_ray_grid(const rt_ray *rays, size_t n, const GridGuess &G, unsigned threads)
+{
+    const size_t nb = G.g[3].size(), na = G.g[2].size(), ny = G.g[1].size();
+    auto bits = [](double v) {
+        const float f = (float) v;
+        uint32_t u;
+        memcpy(&u, &f, sizeof(u));
+        return (uint64_t) u;
+    };
+    std::vector<uint64_t> bx(G.g[0].size()), by(ny), ba(na), bb(nb);
+    for (size_t i = 0; i < bx.size(); i++)
+        bx[i] = bits(G.g[0][i]);
+    for (size_t i = 0; i < ny; i++)
+        by[i] = bits(G.g[1][i]) << 32;
+    for (size_t i = 0; i < na; i++)
+        ba[i] = bits(G.g[2][i]);
+    for (size_t i = 0; i < nb; i++)
+        bb[i] = bits(G.g[3][i]) << 32;
+    const size_t rows = n / nb; // runs of nb rays that differ only in b
+    threads           = threads < 1 ? 1 : threads;
+    if (n < (size_t) 1 << 18)
+        threads = 1;
+    std::atomic<bool> ok(true);
+    auto work = [&](size_t r0, size_t r1) {
+        uint64_t diff = 0;
+        for (size_t r = r0; r < r1; r++) {
+            const size_t k = r % na, j = (r / na) % ny, i = r / (na * ny);
+            const uint64_t xy = bx[i] | by[j], a = ba[k];
+            uint64_t w[2];
+            const unsigned char *row = reinterpret_cast<const unsigned char *>(rays + r * nb);
+            for (size_t m = 0; m < nb; m++) {
+                memcpy(w, row + 16 * m, 16);
+                diff |= (w[0] ^ xy) | (w[1] ^ (a | bb[m]));
+            }
+            if ((r & 1023) == 1023 && (diff != 0 || !ok.load(std::memory_order_relaxed)))
+                break;
+        }
+        if (diff != 0)
+            ok.store(false, std::memory_order_relaxed);
+    };
+    if (threads == 1) {
+        work(0, rows);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < threads; t++)
+            th.emplace_back(work, rows * t / threads, rows * (t + 1) / threads);
+        for (auto &t : th)
+            t.join();
+    }
+    return ok.load();
+}
+
+int plan_set_guessed_grid(rt_hip_plan *p, const GridGuess &G, int64_t first, int64_t count)
+{
+    return rt_hip_plan_set_ray_grid(p, G.g[0].data(), (int) G.g[0].size(), G.g[1].data(), (int) G.g[1].size(),
+                                    G.g[2].data(), (int) G.g[2].size(), G.g[3].data(), (int) G.g[3].size(), first, 1, count);
+}
+
+// x / d for every x < 2^31 as mulhi(x, mul) >> sh (DevRays::div_mul): with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
+// satisfies mul d = 2^(31+s) + e, 0 < e <= d <= 2^s, hence x mul / 2^(31+s) = x / d + x e / (d 2^(31+s)) with the
+// second term below 1 / d: the floor is that of x / d.  mul < 2^32 for d >= 2; d = 1 is flagged by mul = 0.
+void magic_u31(unsigned d, unsigned &mul, unsigned &sh)
+{
+    if (d <= 1) {
+        mul = 0;
+        sh  = 0;
+        return;
+    }
+    unsigned s = 0;
+    while ((1ull << s) < d)
+        s++;
+    mul = (unsigned) ((1ull << (31 + s)) / d + 1);
+    sh  = s - 1;
+}
+
+// RayTraceImageCPU.cpp:11-16 on the host: grid point i (rounded to float, as the ray carries it) must fall in
+// deposit cell i of the grid g with spacing d -- what makes "ray column i deposits into pixel column i" true
+bool grid_points_in_own_cells(const double *g, int n, double d)
+{
+    for (int i = 0; i < n; i++) {
+        const double v = (double) (float) g[i];
+        if (v < g[0] - 0.5 * d || v > g[n - 1] + 0.5 * d)
+            return false;
+        const double t = v - 0.5 * d;
+        int idx        = 0;
+        if (t < g[0])
+            idx = 0;
+        else if (t > g[n - 1])
+            idx = n;
+        else {
+            int lo = 0, hi = n - 1;
+            if (n == 1)
+                hi = 1;
+            while (n > 1 && hi - lo != 1) {
+                int mid = (hi + lo) / 2;
+                if (g[mid] >= t)
+                    hi = mid;
+                else
+                    lo = mid;
+            }
+            idx = hi;
+        }
+        if (idx != i)
+            return false;
+    }
+    return true;
+}
+
+// ---- list-mode launch tangents and the host's libm ------------------------------------------------
+// rt_tan_kernel restates the float tanf of glibc 2.35 (rt_march.hip).  Whether THIS host's tanf is that
+// routine is probed once per process: 8192 angles from 1e-3 mrad to 1.37 rad, both signs, device against
+// host, bit for bit.  If they differ anywhere (another libm), list-mode tangents are computed by the
+// host's tanf on host threads and uploaded -- slower (two libm calls per ray), but the march then starts
+// every ray exactly as RayTraceImageCPULoop on this host does.  (Grid mode always uses the host's tanf.)
+namespace {
+std::atomic<int> g_tan_mode(0); // 0 unknown, 1 device restatement == host tanf, 2 host tangents
+} // namespace
+
+void host_tangents(const rt_ray *rays, size_t n, float *sxy)
+{
+    const unsigned threads = n >= (1u << 16) ? host_threads(16) : 1;
+    auto work = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            sxy[2 * i]     = tanf(1e-3f * rays[i].a); // Helper.h:409-410
+            sxy[2 * i + 1] = tanf(1e-3f * rays[i].b);
+        }
+    };
+    if (threads == 1) {
+        work(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++)
+        th.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+    for (auto &t : th)
+        t.join();
+}
+
+int tan_mode(int device)
+{
+    int m = g_tan_mode.load();
+    if (m != 0)
+        return m;
+    if (getenv("RT_HIP_TAN_ON_HOST")) {
+        g_tan_mode.store(2);
+        return 2;
+    }
+    const size_t n = 8192;
+    std::vector<rt_ray> r(n);
+    for (size_t i = 0; i < n; i++) {
+        // geometric ladder of magnitudes with a wobble in the low bits, alternating signs
+        const double mag = 1e-3 * pow(1.37e6, (double) (i / 2) / (double) (n / 2 - 1)); // mrad: 1e-3 ... 1370
+        const float a    = (float) (mag * (1.0 + 1e-4 * (double) ((i * 2654435761u) & 1023u)));
+        r[i]             = { 0.0f, 0.0f, (i & 1) ? -a : a, (i & 1) ? a : -a };
+    }
+    rt_ray *d_r  = nullptr;
+    float *d_sxy = nullptr;
+    std::vector<float> got(2 * n), want(2 * n);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipMalloc((void **) &d_r, n * sizeof(rt_ray));
+    if (e == hipSuccess)
+        e = hipMalloc((void **) &d_sxy, 2 * n * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(d_r, r.data(), n * sizeof(rt_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess && launch_tan(d_r, (unsigned long long) n, d_sxy, nullptr) != RT_OK)
+        e = hipErrorLaunchFailure;
+    if (e == hipSuccess)
+        e = hipMemcpy(got.data(), d_sxy, 2 * n * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d_r);
+    (void) hipFree(d_sxy);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        return 1; // the probe could not run: the caller's own HIP calls will report what is wrong
+    }
+    host_tangents(r.data(), n, want.data());
+    m = memcmp(got.data(), want.data(), 2 * n * sizeof(float)) == 0 ? 1 : 2;
+    g_tan_mode.store(m);
+    return m;
+}
+
+} // namespace rtr
+
+extern "C" {
+
+int rt_hip_host_libm_mode(int device) { return rtr::tan_mode(device); }
+
+int rt_hip_ray_list_grid_dims(const rt_ray *rays, size_t n_rays, int dims[4])
+{
+    rtr::GridGuess G;
+    if (!rays || !dims || !rtr::guess_ray_grid(rays, n_rays, G) || !rtr::verify_ray_grid(rays, n_rays, G, rtr::host_threads(16)))
+        return 0;
+    for (int i = 0; i < 4; i++)
+        dims[i] = (int) G.g[i].size();
+    return 1;
+}
+
+} // extern "C"

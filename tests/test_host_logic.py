@@ -183,7 +183,7 @@ def test_assembler_single_rank_is_a_view_of_its_buffer(ase_small):
 
 
 def test_magic_number_division_of_ray_numbers_is_exact():
-    """DevRays::div_mul / div_sh (rt_hip.hip, magic_u31): x // d == (x * mul >> 32) >> sh for every x < 2^31, where
+    """DevRays::div_mul / div_sh (rt_raygrid.hip, magic_u31): x // d == (x * mul >> 32) >> sh for every x < 2^31, where
     mul = floor(2^(31+s) / d) + 1, s = ceil(log2 d), sh = s - 1 -- the rule the march uses to split a ray number
     into its grid indices (RayTraceImage.cpp:300-328) without an integer division.  The GPU parity tests cover the
     kernel itself; this pins the arithmetic, including the edge divisors."""
