@@ -170,7 +170,9 @@ struct DevParams {
     // rt_march.hip -> records -> rt_freq.hip
     const unsigned char *blob; // march blob (global copy)
     unsigned int blob_bytes;
-    unsigned int pad2;
+    // 1: never mark a ray F_SKIP (rt_march.hip): a lineshape table holds a NaN or an infinity, and on the CPU even a
+    // ray with all-zero sums reads row ivl = 0 of every table and fails with 0 * NaN (Helper.h:543-594)
+    unsigned int no_skip;
     unsigned char *rec;
     unsigned int rec_stride;
     unsigned int chunk; // rays a wave reserves per fetch of the global ray counter
@@ -221,7 +223,7 @@ enum : unsigned {
     FQ_EXACT_EMIS = 8u,   // DevParams::exact_emis
     FQ_HAS_SEED   = 16u,
     FQ_PROBE      = 32u,
-    FQ_GV_NAN     = 64u,  // some lineshape value is a NaN (found by the host scan): test per frequency
+    FQ_GV_NAN     = 64u,  // some lineshape value is a NaN or an infinity (found by the host scan): test per frequency
     FQ_IANG_LDS   = 128u, // the I_ang histogram of a work-group lives in LDS
     FQ_NEED_EXIT  = 256u, // the exit angles are needed (forward method, seed, or probe)
     FQ_OWN_CELLS  = 512u, // DevParams::own_cells: pixel and angle cell of a ray are its grid indices

@@ -20,6 +20,8 @@
 //           ending in coalesced f64 atomics or stores.  See freq_tile.
 #include "rt_march.hip"
 
+#include <cfloat>
+
 namespace rt {
 
 #ifndef RT_FREQ_WAVES_SEED
@@ -563,8 +565,8 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
 #else
     const bool all_small = all_regular && __ballot(big) == 0ull;
 #endif
-    // a NaN among the lineshape values (the CPU's 0 * NaN) is tested per frequency only when the host
-    // scan of the tables found one
+    // a NaN or an infinity among the lineshape values (the CPU's 0 * NaN, 0 * inf and inf / inf: every one of them
+    // leaves Iv = NaN, Helper.h:549-557) is tested per frequency only when the host scan of the tables found one
     const bool gv_nan = (hflags & FQ_GV_NAN) != 0;
 
     double angsum = 0.0; // RayTraceImageCPU.cpp:63-68, sequential in k like the CPU
@@ -644,12 +646,12 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                             bool wn = false;
 #pragma unroll
                             for (int s = 0; s < SF; s++)
-                                wn = wn || w[s].v[j] != w[s].v[j];
+                                wn = wn || !(fabsf(w[s].v[j]) <= FLT_MAX);
                             Iv[j] = wn ? __builtin_nan("") : Iv[j];
                         }
                     }
                 } else {
-                    bool wnan[VEC]; // a NaN anywhere in this frequency's lineshape values (0 * NaN on the CPU)
+                    bool wnan[VEC]; // a NaN or infinity anywhere in this frequency's lineshape values (0 * NaN on the CPU)
 #pragma unroll
                     for (int j = 0; j < VEC; j++)
                         wnan[j] = false;
@@ -661,7 +663,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                         const FVec w = *reinterpret_cast<const FVec *>(row);
 #pragma unroll
                         for (int j = 0; j < VEC; j++)
-                            wnan[j] = wnan[j] || w.v[j] != w.v[j];
+                            wnan[j] = wnan[j] || !(fabsf(w.v[j]) <= FLT_MAX);
                         if (fabsf(g1) >= RT_RS_MIN && fabsf(g1) <= H.gs_cap && !exact_emis) {
                             const double r1 = div_fast((double) e1, (double) g1);
                             ase_step(Iv, g1, r1, w.v, tab);

@@ -25,6 +25,8 @@
 // as one 96-byte line per ray; rt_freq.hip consumes it with lanes = rays.
 #include "rt_math.h"
 
+#include <cfloat>
+
 namespace rt {
 
 enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 };
@@ -530,6 +532,17 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     sz = -sz;
                 }
                 renormalise(sx, sy, sz);
+                // A NaN in the start of a ray (a NaN or infinite launch angle -- tanf gives NaN for both --, a NaN
+                // position) that does not escape at once: every comparison of the escape test and of the cell box
+                // fails on it, z never advances, and the reference's cell loop (Helper.h:463-504) spins for ever from
+                // the second segment on.  Such a ray is reported as an invalid ray instead (error -1, what
+                // Helper.h:515 reports for a direction it cannot use): no march, direction zeroed so that the
+                // s.z^2 < 0.01 test of the frequency kernel sees it.  (A NaN ray that starts outside the plasma
+                // escapes in the reference as well and is left alone.)
+                const BlobGain G0 = hdr[backward ? P.N - 1 : 1];
+                const float dsum  = sx + sy + sz;
+                const bool wild   = ((px != px) | (py != py) | (dsum != dsum)) &
+                                  !((px < G0.lo_x) | (px > G0.hi_x) | (py < G0.lo_y) | (py > G0.hi_y));
                 if (P.path_on) { // Helper.h:419-426
                     float *pp = P.path + (size_t) ridx * 3 * (size_t) (S + 1) + 3 * (size_t) (backward ? S : 0);
                     pp[0]     = px;
@@ -540,14 +553,17 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 seg       = 0;
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
-                G         = hdr[ii];
+                G         = G0;
                 z         = 0.0f;
                 z_stop    = zs0;
                 gacc      = 0.0f;
                 eacc      = 0.0f;
                 cell_last = 0;
                 steps     = 0;
-                escaped   = false;
+                escaped   = wild; // (an escaped ray commits one empty slot and retires, block [A1])
+                sx        = wild ? 0.0f : sx;
+                sy        = wild ? 0.0f : sy;
+                sz        = wild ? 0.0f : sz;
                 any_bits  = 0;
                 sub       = 0;
                 st        = ST_CELL;
@@ -753,8 +769,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 unsigned fl = F_VALID;
                 if (escaped)
                     fl |= F_ESCAPED;
-                if (use_emis && any_bits == 0u)
-                    fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0
+                if (use_emis && any_bits == 0u && !P.no_skip)
+                    fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0 (finite lineshape)
                 RecMeta m;
                 m.px          = px;
                 m.py          = py;

@@ -446,7 +446,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
                     m          = a > m ? a : m;
                 }
                 umax = m > umax ? m : umax;
-                if (mall > 0x7f800000u) // a NaN: the frequency kernel then tests every value it reads
+                if (mall >= 0x7f800000u) // a NaN or an infinity: the frequency kernel then tests every value it reads
                     p->gv_has_nan = true;
             }
             memcpy(&wmax, &umax, sizeof(wmax));

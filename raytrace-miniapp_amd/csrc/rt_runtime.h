@@ -62,7 +62,7 @@ struct rt_hip_plan {
     // frequency kernel arguments that are not part of DevParams (rt_device.h: FreqHot)
     std::vector<const float *> gv_dev; // [N] lineshape table of every length on the device, entry 0 unused
     const double *dv2_dev = nullptr;   // [Kp] 2 * beam.dv
-    bool gv_has_nan       = false;     // host scan of the lineshape tables (emission mode)
+    bool gv_has_nan       = false;     // host scan of the lineshape tables (emission mode): a NaN or an infinity
     // the refractive-index tables and the segment length lie in the ranges under which the march's divisions
     // need no scaling (rt_march.hip, template parameter BOUNDED); checked by rt_hip_plan_create
     bool tables_bounded   = false;

@@ -1,6 +1,7 @@
 """Edge cases of the HIP path against the oracle, through the C ABI."""
 import copy
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -180,6 +181,73 @@ def test_failure_codes_match_the_cpu_loop(hip, oracle, ase_small):
     same_outputs_in_a_failing_run(out, ref)
     with pytest.raises(hip.RayTraceError, match="Some rays failed"):
         hip.create_image(p, "hip")
+
+
+def _ray_set(rays):
+    return sorted(tuple(np.asarray(r.tolist(), dtype=np.float32).view(np.uint32).tolist()) for r in rays)
+
+
+@pytest.mark.parametrize("bad_value", [np.nan, np.inf])
+def test_non_finite_lineshape_in_row_zero_fails_rays_that_never_entered_the_plasma(hip, oracle, ase_small, bad_value):
+    """Helper.h:543-594: the ASE loop multiplies gvl * gv[k + ivl * K] for EVERY sub-segment, entered or not; a ray
+    that escaped at once has gvl = 0, ivl = 0 everywhere, reads row 0 of every length's table and fails with
+    0 * NaN (or 0 * inf) -> error -3 on the CPU.  The march marks all-zero records `skip` (nothing to integrate)
+    only while every lineshape value is finite; here the only non-finite value sits in row 0 of ONE length and the
+    only rays that meet it are rays that never entered the plasma: failure code and failed rays must be the CPU's."""
+    p = copy.copy(ase_small)
+    g = ase_small.gain[1]
+    gv = g.gv.copy()
+    gv[3] = bad_value                                   # cell 0, frequency 3 of length 1 -- nothing else
+    p.gain = [ase_small.gain[0], rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv), ase_small.gain[2]]
+    rays = np.zeros(20, dtype=rt.cabi.RAY_DTYPE)
+    rays["x"] = 10.0 + np.arange(20)                    # far outside the plasma: escape at the first test
+    rays["y"] = 0.01
+    rays["a"] = np.linspace(-3, 3, 20)
+    out, ref = run_hip(hip, p, rays), oracle.image_loop(p, rays)
+    assert ref["failure_code"] == 1 << 3, "the CPU loop fails these rays with error -3"
+    assert out["failure_code"] == ref["failure_code"]
+    assert _ray_set(out["failed_rays"]) == _ray_set(ref["failed_rays"])
+    same_outputs_in_a_failing_run(out, ref)
+    # the same table with rays that do march: those whose unvisited sub-segments (or visited cells) read row 0
+    ids = np.arange(0, ase_small.n_rays_total, 1499, dtype=np.int64)
+    mixed = np.concatenate([ase_small.build_rays(ids), rays[:3]])
+    out, ref = run_hip(hip, p, mixed), oracle.image_loop(p, mixed)
+    assert out["failure_code"] == ref["failure_code"]
+    if len(ref["failed_rays"]) < rt.cabi.RT_N_FAILED_MAX:
+        assert _ray_set(out["failed_rays"]) == _ray_set(ref["failed_rays"])
+    same_outputs_in_a_failing_run(out, ref)
+    # and a finite table still skips them: no failure, counters say so
+    out = run_hip(hip, ase_small, rays)
+    assert out["failure_code"] == 0 and out["stats"]["n_skipped"] == len(rays)
+
+
+def test_rays_with_a_nan_start_are_reported_as_invalid_not_marched(hip, oracle, ase_small):
+    """A NaN or infinite launch angle (tanf gives NaN for both) or a NaN position inside the plasma: every
+    comparison of the reference's escape test and cell box fails on it, z never advances and its cell loop
+    (Helper.h:463-504) never ends for N >= 3 -- there is no CPU result to compare with.  The backend reports such
+    a ray as an invalid ray (error -1) and marches the others as if it were not there.  The same NaN ray
+    launched outside the plasma escapes at once in the reference too and is no error."""
+    ids = np.arange(0, ase_small.n_rays_total, 1999, dtype=np.int64)
+    good = ase_small.build_rays(ids)
+    wild = good[:4].copy()
+    wild["x"], wild["y"] = 0.5 * (ase_small.gain[1].x[0] + ase_small.gain[1].x[-1]), 0.01
+    wild["a"] = [np.nan, np.inf, 1.0, 1.0]
+    wild["b"] = [0.0, 0.0, -np.inf, 0.0]
+    wild["x"][3] = np.nan
+    outside = good[:1].copy()
+    outside["x"], outside["a"] = 10.0, np.nan
+    for march_ieee in (False, True):
+        if march_ieee:
+            os.environ["RT_HIP_MARCH_IEEE"] = "1"
+        try:
+            out = run_hip(hip, ase_small, np.concatenate([good, wild, outside]))
+        finally:
+            os.environ.pop("RT_HIP_MARCH_IEEE", None)
+        ref = oracle.image_loop(ase_small, np.concatenate([good, outside]))
+        assert out["failure_code"] == 1 << 1 and ref["failure_code"] == 0
+        assert _ray_set(out["failed_rays"]) == _ray_set(wild)
+        assert out["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+        assert rel_l2(out["image"], ref["image"]) < TIGHT and rel_l2(out["I_ang"], ref["I_ang"]) < TIGHT
 
 
 def test_host_pointer_entry_and_create_image_arms(hip, ase_small, ase_ref):
