@@ -180,3 +180,10 @@ def test_bench_two_rank_launch_rehearsal(hip):
     assert line["multi_gpu"]["ranks_seen"] == 2
     assert line["config"]["rays_total"] == 6384000 and line["config"]["ray_steps_total"] == 75601675
     assert line["config"]["rays_per_gpu"] == 3192000
+    # the product's own multi-GPU arm on the same workload (rt_hip_multi_image_loop, ndev = 2; on this one-GPU box the
+    # loop-back rehearsal): present, in tile mode, and equal to the single-device image in the run itself
+    cab = line["multi_gpu"]["cabi"]
+    assert "error" not in cab, cab
+    assert cab["entry"] == "rt_hip_multi_image_loop" and cab["ndev"] == 2 and "tiles" in cab["mode"]
+    assert cab["image_matches_single_device_1e-12"] and cab["ray_steps"] == 75601675 and cab["failure_code"] == 0
+    assert cab["ms_per_image"] > 0 and cab["kernel_ms_max_over_devices"] > 0

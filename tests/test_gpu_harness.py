@@ -22,10 +22,16 @@ def need(exe: Path):
     if exe.exists():
         return
     import json
+    import os
     stamp = ROOT / "oracle" / "ref_build_stamp.json"
     if stamp.exists() and json.loads(stamp.read_text()).get("reference_present"):
         pytest.fail(f"{exe.relative_to(ROOT)} is missing although build() ran with the reference tree present: the "
                     "boundary tests cannot run")
+    if not stamp.exists() and os.environ.get("GRAFT_REPO_ROOT"):
+        # a GPU box runs a snapshot of a tree that build() has been run on where the reference exists: neither the
+        # binaries nor the (git-ignored) stamp arriving means the snapshot lost oracle/_ref/, not that it was never built
+        pytest.fail(f"{exe.relative_to(ROOT)} and oracle/ref_build_stamp.json are both missing on a GPU box "
+                    "(GRAFT_REPO_ROOT is set): the snapshot lost the reference binaries; the boundary tests cannot run")
     pytest.skip(f"{exe.relative_to(ROOT)} was not built (no reference tree where build() ran)")
 
 
