@@ -53,12 +53,17 @@ struct alignas(16) BlobGain {
 // (Helper.h:482-483 and :330-334): the kernel divides by multiplication + exact residual
 // correction (rt_math.h, div_by_recip).
 struct alignas(16) Interval {
-    double lo, hi; // g[u-1], g[u]
-    double rh, rw; // RN(1 / (hi - lo)), RN(1 / (double) (float) (hi - lo))
+    // first 32 bytes: what stays in the lane's registers while the ray is in the cell (two 16-byte reads straight
+    // into the lane state, rt_march.hip block [A2])
+    double lo;     // g[u-1]
+    double rw;     // RN(1 / (double) (float) (hi - lo))
     float w;       // (float) (hi - lo)
     float b_lo;    // (float) (lo - 0.1 (hi - lo)); mirrored y axis, u = 1: -b_hi (Helper.h:494-495)
     float b_hi;    // (float) (hi + 0.1 (hi - lo))
     float pad;
+    // last 16 bytes: used by the cell set-up only
+    double hi;     // g[u]
+    double rh;     // RN(1 / (hi - lo))
 };
 
 struct DevSeed {

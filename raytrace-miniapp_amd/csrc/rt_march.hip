@@ -31,6 +31,10 @@ namespace rt {
 
 enum : int { ST_IDLE = 0, ST_CELL = 1, ST_XSETUP = 2, ST_STEP = 3, ST_DONE = 4 };
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 // grid mode: indices of ray ridx on the four ray grids
 // (RayTraceImage.cpp:300-328: b fastest, then a, y, x)
 __device__ __forceinline__ unsigned div_magic(unsigned x, unsigned mul, unsigned sh)
@@ -196,8 +200,13 @@ __device__ __forceinline__ float tanf_flt32_kernel(float x)
     const float ax = fabsf(x);
     if (ax < 0x1p-13f) // s_tanf.c/k_tanf.c: (int) x == 0 -> return x
         return x;
-    if (ax > 0.2f)
+    if (ax > 0.2f) {
+        // (tanf(+-inf) = NaN, as every libm has it; the device library's f64 tangent must not see an infinity: its
+        // argument reduction indexes a table with the exponent and faulted on it -- found by tests/test_gpu_edges.py)
+        if (!(ax <= FLT_MAX))
+            return x - x;
         return ax <= 1.375f ? tanf_flt32_wide(x) : tan_wide(x);
+    }
     const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
                 T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
                 T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,
@@ -400,6 +409,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         tab = P.blob;
     }
     const BlobGain *hdr = reinterpret_cast<const BlobGain *>(tab);
+    // LDS byte address of the blob, for the hand-written reads of block [A2]
+    const unsigned lds_base = LDS_TAB ? (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) lds_raw : 0u;
 
     // ends of the three sub-segments of a segment, Helper.h:456: dz * (iz + 1) / N_sub
     static_assert(RT_N_SUB == 3, "sub-segment ends are tabulated for three sub-segments");
@@ -438,9 +449,11 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     // rounded to float (Helper.h:332) and as the four f64 edge differences of Helper.h:333-334
     float f00 = 1, f10 = 1, f01 = 1, f11 = 1;
     double dnx0 = 0, dnx1 = 0, dny0 = 0, dny1 = 0; // n10 - n00, n11 - n01, n01 - n00, n11 - n10
-    double xc0 = 0, yc0 = 0;  // lower-left corner coordinates of the current cell
-    double rwx = 1, rwy = 1;  // 1/(double)wx, 1/(double)wy of the current cell
-    float wx = 1, wy = 1, b0 = 0, b1 = 0, b2 = 0, b3 = 0, g0 = 0, E0 = 0;
+    // the two interval records of the current cell as block [A2] reads them, 16 bytes at a time (rt_device.h,
+    // Interval): {lo = lower-left corner coordinate, rw = 1 / (double) w} and {w, b_lo, b_hi, -} per axis
+    f64x2 ix0 = { 0.0, 1.0 }, iy0 = { 0.0, 1.0 };
+    f32x4 ix1 = { 1.0f, 0.0f, 0.0f, 0.0f }, iy1 = { 1.0f, 0.0f, 0.0f, 0.0f };
+    float g0 = 0, E0 = 0;
     float dzrem = 0, zc = 0, path = 0;
     // integrator
     float rx = 0, ry = 0, rz = 0, n = 0, n0 = 0, gxn = 0, gyn = 0, lim2 = 0, dzcap = 0, hsum = 0;
@@ -648,109 +661,92 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     const Interval *ivy = reinterpret_cast<const Interval *>(tab + G.off_iy);
                     // (records are addressed by 32-bit byte offsets from the start of the blob: no
                     // 64-bit multiplies for what is an LDS address)
-                    // One round of gathers per cell: two 48-byte interval records and four 16-byte corner nodes, as
-                    // ten 16-byte LDS reads issued together.  (Left to itself the compiler reads the tail of an
-                    // interval record as ds_read_b96 and a node as b64 + b32 + b32; measured issue cost per LDS
-                    // instruction: b32 / b64 5, b128 10, b96 20 VALU-equivalent ticks -- tools/ubench.)  The
-                    // empty asm statements keep the 16-byte reads whole.
-                    auto read16 = [&](unsigned byte_off) {
-#ifdef RT_ABL_NODES_GLOBAL
-                        return *reinterpret_cast<const uint4 *>(P.blob + byte_off);
-#else
-                        return *reinterpret_cast<const uint4 *>(tab + byte_off);
-#endif
-                    };
-                    auto f64_of = [](unsigned lo, unsigned hi) { return __hiloint2double((int) hi, (int) lo); };
-                    auto gather = [&](int k1, int k2, int c, Interval &X, Interval &Y, Node &n00, Node &n10, Node &n01, Node &n11) {
+                    // One round of gathers per cell: two 48-byte interval records and four 16-byte corner nodes (the
+                    // two nodes of a grid row are neighbours), ten 16-byte reads issued together.  In the LDS variant
+                    // they are written as ds_read_b128 instructions whose results ARE the lane-state registers
+                    // (ix0, ix1, iy0, iy1) or are consumed where they land: left to itself the compiler reads the tail
+                    // of a record as ds_read_b96 and a node as b64 + b32 + b32 (issue cost per LDS instruction: b32 /
+                    // b64 5, b128 10, b96 20 VALU-equivalent ticks -- tools/ubench), and held to whole 16-byte reads
+                    // by empty asm statements (round 3) it paid for them with 34 register copies per cell set-up.
+                    f64x2 tx, ty;            // {hi, rh} of the two intervals
+                    u32x4 q00, q10, q01, q11; // corner nodes {n (f64) | g0 | E0}
+                    auto gather = [&](int k1, int k2, int c) {
                         const unsigned ox = (unsigned) G.off_ix + (unsigned) k1 * (unsigned) sizeof(Interval);
                         const unsigned oy = (unsigned) G.off_iy + (unsigned) k2 * (unsigned) sizeof(Interval);
                         const unsigned oa = (unsigned) G.off_node + (unsigned) c * (unsigned) sizeof(Node);
                         const unsigned ob = oa + (unsigned) G.Nx * (unsigned) sizeof(Node);
-                        uint4 x0 = *reinterpret_cast<const uint4 *>(tab + ox), x1 = *reinterpret_cast<const uint4 *>(tab + ox + 16),
-                              x2 = *reinterpret_cast<const uint4 *>(tab + ox + 32);
-                        uint4 y0 = *reinterpret_cast<const uint4 *>(tab + oy), y1 = *reinterpret_cast<const uint4 *>(tab + oy + 16),
-                              y2 = *reinterpret_cast<const uint4 *>(tab + oy + 32);
-                        uint4 q0 = read16(oa), q1 = read16(oa + 16), q2 = read16(ob), q3 = read16(ob + 16);
-                        asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w),
-                                          "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(y0.x), "+v"(y0.y), "+v"(y0.z), "+v"(y0.w),
-                                          "+v"(y1.x), "+v"(y1.y), "+v"(y1.z), "+v"(y1.w), "+v"(y2.x), "+v"(y2.y), "+v"(y2.z), "+v"(y2.w));
-                        X.lo = f64_of(x0.x, x0.y);
-                        X.hi = f64_of(x0.z, x0.w);
-                        X.rh = f64_of(x1.x, x1.y);
-                        X.rw = f64_of(x1.z, x1.w);
-                        X.w  = __uint_as_float(x2.x);
-                        X.b_lo = __uint_as_float(x2.y);
-                        X.b_hi = __uint_as_float(x2.z);
-                        Y.lo = f64_of(y0.x, y0.y);
-                        Y.hi = f64_of(y0.z, y0.w);
-                        Y.rh = f64_of(y1.x, y1.y);
-                        Y.rw = f64_of(y1.z, y1.w);
-                        Y.w  = __uint_as_float(y2.x);
-                        Y.b_lo = __uint_as_float(y2.y);
-                        Y.b_hi = __uint_as_float(y2.z);
-                        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                                          "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
-                        auto unpack = [&](const uint4 &q) {
-                            Node nd;
-                            nd.n  = f64_of(q.x, q.y);
-                            nd.g0 = __uint_as_float(q.z);
-                            nd.E0 = __uint_as_float(q.w);
-                            return nd;
-                        };
-                        n00 = unpack(q0);
-                        n10 = unpack(q1);
-                        n01 = unpack(q2);
-                        n11 = unpack(q3);
+                        if (LDS_TAB) {
+                            // (lds_raw starts at LDS address 0: the kernel has no static LDS; the reads complete
+                            // inside the statement, so the compiler's own wait counters stay right)
+                            asm volatile("ds_read_b128 %0, %10\n\t"
+                                         "ds_read_b128 %1, %10 offset:16\n\t"
+                                         "ds_read_b128 %2, %10 offset:32\n\t"
+                                         "ds_read_b128 %3, %11\n\t"
+                                         "ds_read_b128 %4, %11 offset:16\n\t"
+                                         "ds_read_b128 %5, %11 offset:32\n\t"
+                                         "ds_read_b128 %6, %12\n\t"
+                                         "ds_read_b128 %7, %12 offset:16\n\t"
+                                         "ds_read_b128 %8, %13\n\t"
+                                         "ds_read_b128 %9, %13 offset:16\n\t"
+                                         "s_waitcnt lgkmcnt(0)"
+                                         : "=&v"(ix0), "=&v"(ix1), "=&v"(tx), "=&v"(iy0), "=&v"(iy1), "=&v"(ty), "=&v"(q00), "=&v"(q10),
+                                           "=&v"(q01), "=&v"(q11)
+                                         : "v"(lds_base + ox), "v"(lds_base + oy), "v"(lds_base + oa), "v"(lds_base + ob));
+                        } else {
+                            const unsigned char *t = tab;
+                            ix0 = *reinterpret_cast<const f64x2 *>(t + ox);
+                            ix1 = *reinterpret_cast<const f32x4 *>(t + ox + 16);
+                            tx  = *reinterpret_cast<const f64x2 *>(t + ox + 32);
+                            iy0 = *reinterpret_cast<const f64x2 *>(t + oy);
+                            iy1 = *reinterpret_cast<const f32x4 *>(t + oy + 16);
+                            ty  = *reinterpret_cast<const f64x2 *>(t + oy + 32);
+                            q00 = *reinterpret_cast<const u32x4 *>(t + oa);
+                            q10 = *reinterpret_cast<const u32x4 *>(t + oa + 16);
+                            q01 = *reinterpret_cast<const u32x4 *>(t + ob);
+                            q11 = *reinterpret_cast<const u32x4 *>(t + ob + 16);
+                        }
                     };
+                    auto node_n = [](const u32x4 &q) { return __hiloint2double((int) q.y, (int) q.x); };
                     const float ya      = mirror ? fabsf(py) : py;
                     const double pxd = (double) px, yad = (double) ya;
                     // one round of gathers on the guessed cell: two interval records, four nodes
                     int k1     = guess_interval(G.Nx, G.x0f, G.inv_hxf, px);
                     int k2     = guess_interval(G.Ny, G.y0f, G.inv_hyf, ya);
                     c00        = (k1 - 1) + (k2 - 1) * G.Nx;
-                    Interval X, Y;
-                    Node a00, a10, a01, a11;
-                    gather(k1, k2, c00, X, Y, a00, a10, a01, a11);
-                    const bool ok = ((k1 == 1) | (X.lo < pxd)) & ((k1 == G.Nx - 1) | (X.hi >= pxd)) &
-                                    ((k2 == 1) | (Y.lo < yad)) & ((k2 == G.Ny - 1) | (Y.hi >= yad));
+                    gather(k1, k2, c00);
+                    const bool ok = ((k1 == 1) | (ix0.x < pxd)) & ((k1 == G.Nx - 1) | (tx.x >= pxd)) &
+                                    ((k2 == 1) | (iy0.x < yad)) & ((k2 == G.Ny - 1) | (ty.x >= yad));
                     if (!ok) {
                         k1  = bisect_interval(ivx, G.Nx, pxd);
                         k2  = bisect_interval(ivy, G.Ny, yad);
                         c00 = (k1 - 1) + (k2 - 1) * G.Nx;
-                        gather(k1, k2, c00, X, Y, a00, a10, a01, a11);
+                        gather(k1, k2, c00);
                     }
-                    f00       = (float) a00.n;
-                    f10       = (float) a10.n;
-                    f01       = (float) a01.n;
-                    f11       = (float) a11.n;
-                    dnx0      = a10.n - a00.n;
-                    dnx1      = a11.n - a01.n;
-                    dny0      = a01.n - a00.n;
-                    dny1      = a11.n - a10.n;
-                    xc0       = X.lo;
-                    yc0       = Y.lo;
-                    rwx       = X.rw;
-                    rwy       = Y.rw;
-                    const float u = (float) div_by_recip<true>(pxd - xc0, X.hi - X.lo, X.rh);
-                    const float v = (float) div_by_recip<true>(yad - yc0, Y.hi - Y.lo, Y.rh);
-                    g0            = lerp2(u, v, a00.g0, a10.g0, a01.g0, a11.g0);
+                    const double n00 = node_n(q00), n10 = node_n(q10), n01 = node_n(q01), n11 = node_n(q11);
+                    f00       = (float) n00;
+                    f10       = (float) n10;
+                    f01       = (float) n01;
+                    f11       = (float) n11;
+                    dnx0      = n10 - n00;
+                    dnx1      = n11 - n01;
+                    dny0      = n01 - n00;
+                    dny1      = n11 - n10;
+                    const float u = (float) div_by_recip<true>(pxd - ix0.x, tx.x - ix0.x, tx.y);
+                    const float v = (float) div_by_recip<true>(yad - iy0.x, ty.x - iy0.x, ty.y);
+                    g0            = lerp2(u, v, __uint_as_float(q00.z), __uint_as_float(q10.z), __uint_as_float(q01.z),
+                                          __uint_as_float(q11.z));
                     E0            = 0.0f;
                     if (use_emis) {
-                        E0 = lerp2(u, v, a00.E0, a10.E0, a01.E0, a11.E0);
+                        E0 = lerp2(u, v, __uint_as_float(q00.w), __uint_as_float(q10.w), __uint_as_float(q01.w),
+                                   __uint_as_float(q11.w));
                         E0 = E0 >= 0 ? E0 : 0.0f;
                     }
-                    wx = X.w; // Helper.h:323-324
-                    wy = Y.w;
-                    b0 = X.b_lo;
-                    b1 = X.b_hi;
-                    b2 = Y.b_lo;
-                    b3 = Y.b_hi;
                     pz    = 0.0f;
                     zc    = 0.0f;
                     path  = 0.0f;
                     dzrem = z_stop - z;
                     // Helper.h:327 with zc = 0: 0.0 < 0.999 * (double) dzrem <=> dzrem > 0 (no underflow in double)
-                    if ((px > b0) & (px < b1) & (ya > b2) & (ya < b3) & (dzrem > 0.0f)) {
+                    if ((px > ix1.y) & (px < ix1.z) & (ya > iy1.y) & (ya < iy1.z) & (dzrem > 0.0f)) {
                         st = ST_XSETUP;
                     } else {
                         // no cross-cell iteration at all: the cell step still counts (Helper.h:498-503)
@@ -805,7 +801,8 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
             const float ya   = mirror ? fabsf(py) : py;
-            const double dwx = (double) wx, dwy = (double) wy;
+            const double dwx = (double) ix1.x, dwy = (double) iy1.x; // Helper.h:323-324
+            const double xc0 = ix0.x, yc0 = iy0.x, rwx = ix0.y, rwy = iy0.y;
             const float u    = (float) div_by_recip<true>((double) px - xc0, dwx, rwx);
             const float v    = (float) div_by_recip<true>((double) ya - yc0, dwy, rwy);
             n0  = lerp2(u, v, f00, f10, f01, f11);
@@ -829,7 +826,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         RT_MARK(4); // [B]
         // ------------------------------------------------------------ [C] one integrator step (Helper.h:279-311)
         if (st == ST_STEP) {
-            const float lim0 = 0.1f * wx, lim1 = 0.1f * wy;
+            const float lim0 = 0.1f * ix1.x, lim1 = 0.1f * iy1.x;
             // The loop condition of Helper.h:279-280 holds for every lane that arrives here: a lane from [B]
             // has r = 0, n = n0 and limits that are positive (cell widths are, rt_hip_plan_create checks it;
             // lim2 = dzrem - zc > 0 is the entry condition of [B]); a lane that stays in this state was
@@ -925,7 +922,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 pz += rz;
                 zc += fabsf(rz);
                 const float ya = mirror ? fabsf(py) : py;
-                if ((px > b0) & (px < b1) & (ya > b2) & (ya < b3) & ((double) zc < 0.999 * (double) dzrem)) {
+                if ((px > ix1.y) & (px < ix1.z) & (ya > iy1.y) & (ya < iy1.z) & ((double) zc < 0.999 * (double) dzrem)) {
                     st = ST_XSETUP;
                 } else {
                     // cross-cell loop over: close the cell step (Helper.h:499-503)

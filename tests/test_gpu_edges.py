@@ -230,12 +230,13 @@ def test_rays_with_a_nan_start_are_reported_as_invalid_not_marched(hip, oracle, 
     ids = np.arange(0, ase_small.n_rays_total, 1999, dtype=np.int64)
     good = ase_small.build_rays(ids)
     wild = good[:4].copy()
-    wild["x"], wild["y"] = 0.5 * (ase_small.gain[1].x[0] + ase_small.gain[1].x[-1]), 0.01
+    g1 = ase_small.gain[1]
+    wild["x"], wild["y"] = 0.5 * (g1.x[0] + g1.x[-1]), 0.5 * g1.y[-1]       # inside the plasma
     wild["a"] = [np.nan, np.inf, 1.0, 1.0]
     wild["b"] = [0.0, 0.0, -np.inf, 0.0]
     wild["x"][3] = np.nan
-    outside = good[:1].copy()
-    outside["x"], outside["a"] = 10.0, np.nan
+    outside = good[:2].copy()
+    outside["x"], outside["a"] = 10.0, [np.nan, np.inf]
     for march_ieee in (False, True):
         if march_ieee:
             os.environ["RT_HIP_MARCH_IEEE"] = "1"
