@@ -222,6 +222,13 @@ int rt_hip_plan_kernel_ms(rt_hip_plan *plan, float *ms);
  * deposit kernel (rt_freq_kernel) of the last run. */
 int rt_hip_plan_kernel_times(rt_hip_plan *plan, float *march_ms, float *freq_ms);
 
+/* 1 if the plan's last run took the whole path in ONE launch (march and frequency pass as two phases of the same
+ * persistent waves, raytrace-miniapp_amd/csrc/rt_fused.hip -- the shape of the reference's own GPU kernel,
+ * src/RayTraceImageCuda.cu:66-127, in behaviour only): march_ms is then the time of that launch and freq_ms 0.
+ * Taken for the emission mode on the beam's own ray grid when the frequency pass fits into LDS beside the march
+ * tables; RT_HIP_FUSED=2 in the environment keeps the two-kernel run. */
+int rt_hip_plan_last_fused(rt_hip_plan *plan);
+
 /* Timing many back-to-back runs without waiting for each: keep the event triples of the last n_runs runs
  * (1 <= n_runs <= 4096); rt_hip_plan_ring_times waits for the last run and returns the kernel durations of
  * the most recent runs, oldest first (at most max_runs of them; *n_runs = how many).  Without a ring a plan

@@ -189,6 +189,10 @@ class Plan:
                       "rt_hip_plan_kernel_times")
         return float(a.value), float(f.value)
 
+    def last_fused(self) -> bool:
+        """The last run took the whole path in one launch (rt_fused.hip): kernel_times() = (launch, 0)."""
+        return bool(self.hl.lib.rt_hip_plan_last_fused(self._h))
+
     def set_timing_ring(self, n_runs: int) -> "Plan":
         """Keep the kernel-event triples of the last n_runs runs (include/rt_hip.h)."""
         self.hl.check(self.hl.lib.rt_hip_plan_set_timing_ring(self._h, int(n_runs)), "rt_hip_plan_set_timing_ring")

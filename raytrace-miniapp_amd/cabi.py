@@ -160,6 +160,8 @@ def declare_hip_api(lib: C.CDLL) -> None:
     lib.rt_hip_plan_kernel_ms.restype = C.c_int
     lib.rt_hip_plan_kernel_times.argtypes = [vp, P(C.c_float), P(C.c_float)]
     lib.rt_hip_plan_kernel_times.restype = C.c_int
+    lib.rt_hip_plan_last_fused.argtypes = [vp]
+    lib.rt_hip_plan_last_fused.restype = C.c_int
     lib.rt_hip_plan_set_timing_ring.argtypes = [vp, C.c_int]
     lib.rt_hip_plan_set_timing_ring.restype = C.c_int
     lib.rt_hip_plan_ring_times.argtypes = [vp, c_float_p, c_float_p, C.c_int, P(C.c_int)]
@@ -192,7 +194,7 @@ HIP_API_SYMBOLS = [
     "rt_hip_device_count", "rt_hip_last_error", "rt_hip_selftest", "rt_hip_image_loop", "rt_hip_multi_image_loop",
     "rt_hip_multi_last_mode", "rt_hip_ray_list_grid_dims", "rt_hip_host_libm_mode", "rt_hip_pool_trim", "rt_hip_plan_create",
     "rt_hip_plan_set_rays", "rt_hip_plan_set_ray_grid", "rt_hip_plan_run", "rt_hip_plan_fetch",
-    "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_set_timing_ring", "rt_hip_plan_ring_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
+    "rt_hip_plan_kernel_ms", "rt_hip_plan_kernel_times", "rt_hip_plan_last_fused", "rt_hip_plan_set_timing_ring", "rt_hip_plan_ring_times", "rt_hip_plan_image_ptr", "rt_hip_plan_iang_ptr", "rt_hip_plan_enable_probe",
     "rt_hip_plan_fetch_probe", "rt_hip_plan_set_exact_emission", "rt_hip_plan_set_step_factor", "rt_hip_plan_enable_path",
     "rt_hip_plan_fetch_path", "rt_hip_plan_set_debug", "rt_hip_plan_destroy",
 ]

@@ -259,8 +259,9 @@ __device__ __forceinline__ int deposit_index_fast(int n, const double *g, double
         return n;
     if (n < 2)
         return n;
-    int u = (int) ((t - g0) * inv_d) + 1; // a guess: the two inequalities below decide
-    u     = u < 1 ? 1 : (u > n - 1 ? n - 1 : u);
+    // a guess: the two inequalities below decide (clamped as a double: an infinite or huge v must not reach the
+    // conversion, whose overflow is undefined -- the compiler may drop the integer clamp behind it)
+    int u = (int) fmin(fmax((t - g0) * inv_d, 0.0), (double) (n - 2)) + 1;
     // first_not_below on [g0, gl]: unique u in [1, n-1] with g[u-1] < t <= g[u]
     // (u = 1 also when t == g0, where the bisection never tests g[0])
     if ((u == 1 || g[u - 1] < t) && g[u] >= t)
@@ -284,9 +285,11 @@ __device__ __forceinline__ void deposit_index4(const AxisIn (&A)[4], int (&idx)[
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         t[a]   = A[a].v - 0.5 * A[a].d;
-        int uu = (int) ((t[a] - A[a].g0) * A[a].inv_d) + 1; // a guess (NaN or out of range: clamped, decided below)
+        // a guess (NaN or out of range: clamped, decided below).  Clamped as a double: an infinite or huge coordinate
+        // must not reach the conversion -- its overflow is undefined and the compiler may then drop an integer clamp
+        // behind it (a ray launched at a = +inf read the grid two billion entries off; tests/test_gpu_edges.py)
         const int last = A[a].n - 1;
-        uu   = uu < 1 ? 1 : (uu > last ? last : uu);
+        const int uu   = (int) fmin(fmax((t[a] - A[a].g0) * A[a].inv_d, 0.0), (double) (last > 0 ? last - 1 : 0)) + 1;
         u[a] = A[a].n >= 2 ? uu : 0;
     }
 #pragma unroll

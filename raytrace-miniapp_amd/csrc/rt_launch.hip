@@ -8,6 +8,7 @@
 // rt_runtime.h.
 #include "rt_path.hip" // debug path tracer (before rt_freq.hip: no FMA contraction there)
 #include "rt_freq.hip" // kernel B (includes rt_march.hip, kernel A)
+#include "rt_fused.hip" // both as two phases of one launch
 
 #include "rt_runtime.h"
 
@@ -34,6 +35,57 @@ template <class Kernel> int allow_lds(Kernel kernel, int device, size_t bytes, s
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) want));
     allowed[(size_t) device] = want;
     return RT_OK;
+}
+
+// the frequency pass's own argument block (rt_device.h): hot = what the frequency loop reads, cold = what the
+// per-ray preamble of a tile reads
+rt::FreqKArg freq_args(const rt_hip_plan *p, bool iang_in_lds, int nslot, unsigned long long grid_waves)
+{
+    const rt::DevParams &P = p->P;
+    rt::FreqKArg a;
+    memset(&a, 0, sizeof(a));
+    a.hot.gv0        = p->gv_dev.size() > 1 ? p->gv_dev[1] : nullptr;
+    a.hot.gv1        = p->gv_dev.size() > 2 ? p->gv_dev[2] : nullptr;
+    a.hot.gain       = P.gain;
+    a.hot.rec        = P.rec;
+    a.hot.image      = P.image;
+    a.hot.iang       = P.iang;
+    a.hot.ctl        = P.ctl;
+    a.hot.dv2        = p->dv2_dev;
+    a.hot.seed_fk    = P.has_seed ? P.seed.f[4] : nullptr;
+    a.hot.bad        = P.bad;
+    a.hot.scale      = P.scale;
+    a.hot.gs_cap     = P.gs_cap;
+    a.hot.K          = P.K;
+    a.hot.Kp         = P.Kp;
+    a.hot.L          = P.L;
+    a.hot.method     = P.method;
+    a.hot.rec_stride = P.rec_stride;
+    a.hot.n_rays     = (unsigned) P.rays.count;
+    a.hot.tile_begin = P.tile_begin;
+    a.hot.tile_end   = P.tile_end;
+    a.hot.freq_id    = P.freq_id;
+    {
+        unsigned sh = 0;
+        while ((1ull << sh) < 2ull * grid_waves) // 2 x waves
+            sh++;
+        a.hot.fetch_shift = sh;
+    }
+    a.hot.nslot      = nslot;
+    a.hot.nx         = P.beam.nx;
+    a.hot.ny         = P.beam.ny;
+    a.hot.n_ang      = P.beam.na * P.beam.nb;
+    a.hot.flags      = (P.exclusive ? rt::FQ_EXCLUSIVE : 0u) | (P.safe == 1 ? rt::FQ_SAFE_CHECK : 0u) |
+                  (P.safe == 2 ? rt::FQ_SAFE_SKIP : 0u) | (P.exact_emis ? rt::FQ_EXACT_EMIS : 0u) |
+                  (P.has_seed ? rt::FQ_HAS_SEED : 0u) | (P.probe_on ? rt::FQ_PROBE : 0u) |
+                  (p->gv_has_nan ? rt::FQ_GV_NAN : 0u) | (iang_in_lds ? rt::FQ_IANG_LDS : 0u) |
+                  ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u) |
+                  (P.own_cells ? rt::FQ_OWN_CELLS : 0u) | ((P.debug & 4u) ? rt::FQ_DBG_NOFLUSH : 0u);
+    a.cold.beam  = P.beam;
+    a.cold.seed  = P.seed;
+    a.cold.rays  = P.rays;
+    a.cold.probe = P.probe;
+    return a;
 }
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
@@ -82,52 +134,7 @@ template <int SF, bool EMIS> int launch_freq(rt_hip_plan *p, hipStream_t stream,
         cap = cap_blocks;
     const unsigned grid = (unsigned) (want < cap ? want : cap);
     if (grid > 0) {
-        // the kernel's own argument block (rt_device.h): hot = what the frequency loop reads, cold = what the
-        // per-ray preamble of a tile reads
-        const rt::DevParams &P = p->P;
-        rt::FreqKArg a;
-        memset(&a, 0, sizeof(a));
-        a.hot.gv0        = p->gv_dev.size() > 1 ? p->gv_dev[1] : nullptr;
-        a.hot.gv1        = p->gv_dev.size() > 2 ? p->gv_dev[2] : nullptr;
-        a.hot.gain       = P.gain;
-        a.hot.rec        = P.rec;
-        a.hot.image      = P.image;
-        a.hot.iang       = P.iang;
-        a.hot.ctl        = P.ctl;
-        a.hot.dv2        = p->dv2_dev;
-        a.hot.seed_fk    = P.has_seed ? P.seed.f[4] : nullptr;
-        a.hot.bad        = P.bad;
-        a.hot.scale      = P.scale;
-        a.hot.gs_cap     = P.gs_cap;
-        a.hot.K          = P.K;
-        a.hot.Kp         = P.Kp;
-        a.hot.L          = P.L;
-        a.hot.method     = P.method;
-        a.hot.rec_stride = P.rec_stride;
-        a.hot.n_rays     = (unsigned) P.rays.count;
-        a.hot.tile_begin = P.tile_begin;
-        a.hot.tile_end   = P.tile_end;
-        a.hot.freq_id    = P.freq_id;
-        {
-            unsigned sh = 0;
-            while ((1ull << sh) < 2ull * grid * (unsigned long long) wg_waves) // 2 x waves
-                sh++;
-            a.hot.fetch_shift = sh;
-        }
-        a.hot.nslot      = nslot;
-        a.hot.nx         = P.beam.nx;
-        a.hot.ny         = P.beam.ny;
-        a.hot.n_ang      = P.beam.na * P.beam.nb;
-        a.hot.flags      = (P.exclusive ? rt::FQ_EXCLUSIVE : 0u) | (P.safe == 1 ? rt::FQ_SAFE_CHECK : 0u) |
-                      (P.safe == 2 ? rt::FQ_SAFE_SKIP : 0u) | (P.exact_emis ? rt::FQ_EXACT_EMIS : 0u) |
-                      (P.has_seed ? rt::FQ_HAS_SEED : 0u) | (P.probe_on ? rt::FQ_PROBE : 0u) |
-                      (p->gv_has_nan ? rt::FQ_GV_NAN : 0u) | (in_lds ? rt::FQ_IANG_LDS : 0u) |
-                      ((P.method != 1 || P.has_seed || P.probe_on) ? rt::FQ_NEED_EXIT : 0u) |
-                      (P.own_cells ? rt::FQ_OWN_CELLS : 0u) | ((P.debug & 4u) ? rt::FQ_DBG_NOFLUSH : 0u);
-        a.cold.beam  = P.beam;
-        a.cold.seed  = P.seed;
-        a.cold.rays  = P.rays;
-        a.cold.probe = P.probe;
+        const rt::FreqKArg a = freq_args(p, in_lds != 0, nslot, (unsigned long long) grid * (unsigned) wg_waves);
         if (lds > p->lds_limit) {
             char msg[256];
             snprintf(msg, sizeof(msg), "frequency kernel: %zu bytes of LDS per work-group (I_ang histogram of %zu cells, %d waves) "
@@ -306,6 +313,65 @@ int plan_run_split(rt_hip_plan *p, hipStream_t stream)
     if (p->host_rays)
         n_launch = env_unsigned("RT_HIP_UPLOAD_SLICES", n_launch, 1, 8); // tuning
     n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
+    // ---- the whole path in ONE launch (rt_fused.hip) where it applies: emission mode on the beam's own ray grid
+    // with at least 32 rays per pixel (a 64-ray tile then spans at most three pixels: the few-runs deposit, which
+    // needs no row cache), tables in LDS, nothing that wants the march records to itself (probe, path tracer,
+    // the checking repeat, profiling switches), and room in LDS for the frequency pass beside the tables
+    p->last_fused = false;
+    if (lds_tab && n_launch == 1 && grid > 0 && !p->path_on && !p->probe_on && p->P.debug == 0 && p->P.use_emis &&
+        !p->P.exclusive && p->P.safe == 0 && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32 &&
+        p->n_iang * sizeof(double) <= 32 * 1024 && env_unsigned("RT_HIP_FUSED", 1, 1, 2) == 1) {
+        const unsigned nw       = bthr / 64;
+        const size_t per_wave   = (size_t) rt::FREQ_WAVE_XPOSE; // doubles: transposition rows + window totals, no row cache
+        rt::FusedLay lay;
+        lay.off_exp  = (unsigned) align_up(p->P.blob_bytes, 16);
+        lay.off_iang = lay.off_exp + 2u * rt::EXP_TAB * (unsigned) sizeof(double);
+        lay.off_ctl  = lay.off_iang + (unsigned) (((p->n_iang + 1) & ~(size_t) 1) * sizeof(double));
+        lay.off_rem  = lay.off_ctl + 16u;
+        lay.off_buf  = lay.off_rem + nw * 32u * (unsigned) sizeof(unsigned);
+        lay.per_wave = (unsigned) per_wave;
+        const size_t room = p->lds_limit > lay.off_buf ? (p->lds_limit - lay.off_buf) / (per_wave * sizeof(double)) : 0;
+        lay.n_free        = (unsigned) (room < nw ? room : nw);
+        const bool fits   = 2 * lay.n_free >= nw && (size_t) (nw - lay.n_free) * per_wave * sizeof(double) <= p->P.blob_bytes;
+        if (fits) {
+            const size_t flds     = (size_t) lay.off_buf + (size_t) lay.n_free * per_wave * sizeof(double);
+            const size_t n_tiles  = (size_t) p->P.n_tiles;
+            if (p->tile_next_n < n_tiles || !p->tile_next) {
+                plan_quiesce(p);
+                pool_free(p->device, p->tile_next);
+                p->tile_next = nullptr;
+                HIP_TRY(pool_alloc(p->device, (void **) &p->tile_next, n_tiles * sizeof(unsigned) + 16));
+                p->tile_next_n = n_tiles;
+            }
+            p->P.ray_begin = 0;
+            p->P.ray_end   = (unsigned) p->n_rays;
+            p->P.launch_id = 0;
+            p->P.chunk     = (p->P.chunk + 32) / 64 * 64; // whole tiles per reservation (64 ... 192 rays)
+            p->P.chunk     = p->P.chunk < 64 ? 64 : p->P.chunk;
+            p->P.tile_begin = 0;
+            p->P.tile_end   = p->P.n_tiles;
+            p->P.freq_id    = 0;
+            rt::FusedKArg fa;
+            fa.P         = p->P;
+            fa.F         = freq_args(p, true, 0, (unsigned long long) grid * nw);
+            fa.tile_next = p->tile_next;
+            fa.lay       = lay;
+            const int S  = p->P.L * RT_N_SUB;
+            using fused_fn = void (*)(const rt::FusedKArg);
+            const fused_fn fk = S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6> : rt::rt_fused_kernel<false, 6>)
+                                       : (bounded ? rt::rt_fused_kernel<true, 0> : rt::rt_fused_kernel<false, 0>);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int) flds));
+            unsigned long long fwant = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
+            const unsigned fgrid     = (unsigned) (fwant < (unsigned long long) p->cu_count ? fwant : (unsigned long long) p->cu_count);
+            hipLaunchKernelGGL(fk, dim3(fgrid), dim3(bthr), flds, stream, fa);
+            HIP_TRY(hipGetLastError());
+            p->host_rays = nullptr;
+            HIP_TRY(hipEventRecord(p->evm, stream));
+            HIP_TRY(hipEventRecord(p->ev1, stream));
+            p->last_fused = true;
+            return RT_OK;
+        }
+    }
     for (unsigned c = 0; c < n_launch && grid > 0 && !(p->P.debug & 2u); c++) {
         const unsigned long long b = p->n_rays * c / n_launch, e = p->n_rays * (c + 1) / n_launch;
         if (p->host_rays) {

@@ -350,9 +350,8 @@ __device__ __forceinline__ int bisect_interval(const Interval *iv, int n, double
 __device__ __forceinline__ int guess_interval(int n, float g0, float inv_h, float v)
 {
     // a guess only (the caller verifies it against the interval's own coordinates): float is enough
-    const int last = n - 1;
-    int u          = (int) ((v - g0) * inv_h) + 1;
-    return u < 1 ? 1 : (u > last ? last : u);
+    // (clamped as a float, before the conversion: the overflow of the conversion itself would be undefined)
+    return (int) fminf(fmaxf((v - g0) * inv_h, 0.0f), (float) (n - 2)) + 1;
 }
 
 // BOUNDED: rt_hip_plan_create has verified the table and step-size ranges under which the integrator's five
@@ -365,10 +364,45 @@ __device__ unsigned short g_ray_iters[1u << 23]; // diagnostic: loop iterations 
 __device__ unsigned long long g_wt[8];
 __device__ unsigned long long g_wt_end[8192], g_wt_dry[8192];
 #endif
-template <bool LDS_TAB, bool BOUNDED>
-__global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
+// Work-group list of finished tiles of the fused kernel (rt_fused.hip): a wave that has marched all 64 rays of a
+// chunk -- one tile of the frequency pass -- pushes the tile number; waves whose rays have run out pop tiles and run
+// their frequency pass.  A lock-free stack: the head is an LDS word, the links are one word per tile in global
+// memory (`next`); tiles are pushed once and never pushed again, so a pop cannot meet a recycled node.
+struct TileList {
+    unsigned *head; // LDS
+    unsigned *next; // global, [n_tiles]
+    unsigned *rem;  // LDS, [32] per wave: rays of the wave's tiles in flight that have not retired yet
+};
+constexpr unsigned TILE_NONE = 0xffffffffu;
+// one lane of the calling wave executes these
+__device__ __forceinline__ void tile_push(const TileList &T, unsigned tile)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned old = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+        __hip_atomic_store(&T.next[tile], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (pushed and popped by waves of one work-group)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the link is in memory before the head can name the tile
+        if (__hip_atomic_compare_exchange_strong(T.head, &old, tile, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+            return;
+    }
+}
+__device__ __forceinline__ unsigned tile_pop(const TileList &T)
+{
+    unsigned old = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (old != TILE_NONE) {
+        const unsigned nxt = __hip_atomic_load(&T.next[old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_compare_exchange_strong(T.head, &old, nxt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+            break;
+    }
+    return old;
+}
+
+// The march of one wave over the rays of a launch.  FUSED (rt_fused.hip): the reserved chunks are whole 64-ray tiles
+// (P.ray_begin = 0, P.chunk a multiple of 64) and are handed to the lanes tile by tile; every tile in flight has a
+// counter of its rays that have not retired (done.rem, one of 32 slots of this wave), and the wave pushes the tile
+// onto `done` when the counter reaches zero and all its record stores have landed.
+template <bool LDS_TAB, bool BOUNDED, bool FUSED>
+__device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *lds_raw, const TileList done)
+{
     const int lane        = lane_id();
     const int L           = P.L;
     const int S           = L * RT_N_SUB;
@@ -421,6 +455,9 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
     asm volatile("" : "+v"(zs0), "+v"(zs1), "+v"(zs2));
 
     unsigned chunk_next = 0, chunk_end = 0; // wave-uniform window of reserved ray indices
+    // FUSED: the window is the part of ONE tile not handed out yet; the reservation it was cut from ends at fetched_end
+    unsigned fetched_end = 0, slot_busy = 0, cur_slot = 0; // (wave-uniform) slots of done.rem in use; slot of the window's tile
+    unsigned cslot       = 0;                               // (per lane) slot of the tile of the lane's ray
     bool more           = true;             // wave-uniform: the ray counters are not exhausted
     // The rays of a launch are handed out in chunks of CH by eight counters (shard sh owns the chunks sh, sh + 8,
     // ...; a wave starts on shard blockIdx.x % 8 and moves on when its own is empty): one counter serves ~88
@@ -492,7 +529,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             int need = n_idle, off = 0;
             bool got = false;
             while (need > 0) {
-                if (chunk_next == chunk_end) {
+                if (chunk_next == chunk_end && !(FUSED && chunk_next != fetched_end)) {
                     unsigned c = 0;
 #ifdef RT_MARCH_ONE_COUNTER // experiment: one counter for all waves
                     if (lane == 0)
@@ -517,12 +554,29 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                     }
                     chunk_next = P.ray_begin + c * CH;
                     chunk_end  = (n_rays - chunk_next < CH) ? n_rays : chunk_next + CH;
+                    if (FUSED) {
+                        fetched_end = chunk_end;
+                        chunk_end   = chunk_next; // (no tile of the reservation is open yet)
+                    }
+                }
+                if (FUSED && chunk_next == chunk_end) {
+                    // open the next tile of the reservation: a free counter slot, loaded with the tile's ray count
+                    const int fs = __builtin_ffs((int) ~slot_busy) - 1;
+                    if (fs < 0)
+                        break; // 32 tiles of this wave in flight (never observed): no new rays until one completes
+                    chunk_end = fetched_end - chunk_next < (unsigned) WAVE ? fetched_end : chunk_next + (unsigned) WAVE;
+                    cur_slot  = (unsigned) fs;
+                    slot_busy |= 1u << fs;
+                    if (lane == 0)
+                        __hip_atomic_store(&done.rem[fs], chunk_end - chunk_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 int avail = (int) (chunk_end - chunk_next);
                 int take  = avail < need ? avail : need;
                 if (st == ST_IDLE && !got && rank >= off && rank < off + take) {
                     ridx = chunk_next + (unsigned) (rank - off);
                     got  = true;
+                    if (FUSED)
+                        cslot = cur_slot;
                 }
                 chunk_next += (unsigned) take;
                 need -= take;
@@ -611,6 +665,7 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
             park_at          = fifth < (int) P.park ? fifth : (int) P.park;
         }
         const bool do_a = (int) __popcll(want_a) >= park_at || (~(idle2 | want_a)) == 0ull;
+        bool last_of_tile = false; // FUSED: the lane's ray ends in this iteration and was the last one of its tile
         if (do_a && st == ST_CELL) {
             bool in_seg        = !escaped & (z < 0.995f * z_stop);
             if (!in_seg) {
@@ -794,9 +849,23 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
                 tot_skip += (fl & F_SKIP) ? 1u : 0u;
                 tot_rays++;
                 st = ST_IDLE;
+                if (FUSED) // one ray of the lane's tile less; the lane that takes the counter to zero has finished the tile
+                    last_of_tile = __hip_atomic_fetch_add(&done.rem[cslot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 1u;
             }
         }
-
+        if (FUSED) {
+            unsigned long long lm = __ballot(last_of_tile);
+            if (lm != 0ull) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's record stores have landed
+                do {
+                    const int l0 = (int) __ffsll((long long) lm) - 1;
+                    lm &= lm - 1ull;
+                    if (lane == l0)
+                        tile_push(done, ridx >> 6);
+                    slot_busy &= ~(1u << (unsigned) __builtin_amdgcn_readlane((int) cslot, l0));
+                } while (lm != 0ull);
+            }
+        }
         RT_MARK(3); // DONE
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
@@ -981,6 +1050,13 @@ __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const De
         }
 #endif
     }
+}
+
+template <bool LDS_TAB, bool BOUNDED>
+__global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    march_wave<LDS_TAB, BOUNDED, false>(P, lds_raw, TileList{ nullptr, nullptr, nullptr });
 }
 
 } // namespace rt

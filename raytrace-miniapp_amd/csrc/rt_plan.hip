@@ -114,6 +114,7 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
     pool_free(p->device, p->image_own);
     pool_free(p->device, p->iang_own);
     pool_free(p->device, p->ctl);
+    pool_free(p->device, p->tile_next);
     (void) hipFree(p->probe);
     (void) hipFree(p->bad_dev);
     delete p;
@@ -876,6 +877,8 @@ int rt_hip_plan_kernel_times(rt_hip_plan *p, float *march_ms, float *freq_ms)
     HIP_TRY(hipEventElapsedTime(freq_ms, p->evm, p->ev1));
     return RT_OK;
 }
+
+int rt_hip_plan_last_fused(rt_hip_plan *p) { return p && p->ran && p->last_fused ? 1 : 0; }
 
 double *rt_hip_plan_image_ptr(rt_hip_plan *p) { return p ? p->image_own : nullptr; }
 double *rt_hip_plan_iang_ptr(rt_hip_plan *p) { return p ? p->iang_own : nullptr; }

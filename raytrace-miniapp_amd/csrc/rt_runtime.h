@@ -66,6 +66,10 @@ struct rt_hip_plan {
     // the refractive-index tables and the segment length lie in the ranges under which the march's divisions
     // need no scaling (rt_march.hip, template parameter BOUNDED); checked by rt_hip_plan_create
     bool tables_bounded   = false;
+    // links of the fused kernel's work-group tile lists (rt_fused.hip), one word per 64-ray tile; last run fused?
+    unsigned *tile_next   = nullptr;
+    size_t tile_next_n    = 0;
+    bool last_fused       = false;
     // LDS a work-group may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KB on gfx950)
     size_t lds_limit      = 0;
 };

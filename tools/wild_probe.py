@@ -15,6 +15,9 @@ elif case == "b_ninf": r["b"] = -np.inf
 elif case == "x_nan": r["x"] = np.nan
 elif case == "a_big": r["a"] = 5000.0          # 5 rad: the f64 tangent stands in (tan_wide)
 elif case == "outside_nan": r["x"], r["a"] = 10.0, np.nan
+elif case == "outside_inf": r["x"], r["a"] = 10.0, np.inf
+elif case == "a_huge": r["a"] = 1e30
+elif case == "outside_huge": r["x"], r["a"] = 10.0, -1e30
 elif case == "good": r = good[:1].copy()
 rays = np.concatenate([good, r]) if "--mixed" in sys.argv else r
 with be.Plan(p) as plan:
