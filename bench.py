@@ -11,8 +11,9 @@ N > 1 may be started either way:
   * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` -- one rank
     per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-A *step* is one pass of the hot path (zero outputs + march kernel + frequency kernel [+ the RCCL
-assembly of the image tiles when N > 1]) over the workload, every input resident in HBM.
+A *step* is one pass of the hot path (zero outputs + march + frequency pass -- one launch, rt_fused.hip, where
+it applies, else two -- [+ the RCCL assembly of the image tiles when N > 1]) over the workload, every input
+resident in HBM.
 
 Workloads (BASELINE.json `configs`):
   standin      configs[2]/[3], the metric's workload: ASE_medium.dat is absent from the reference
@@ -624,6 +625,7 @@ def main() -> int:
     dt = time.perf_counter() - t0
 
     kms = plan.ring_times()  # (march_ms, freq_ms) of the timed steps, recorded on the launch stream
+    fused = plan.last_fused()  # one launch for the whole path: the first time is the launch's, the second ~0
 
     st = plan.fetch(want_image=False)
     stats = st["stats"]
@@ -738,7 +740,14 @@ def main() -> int:
                 r["secondary"] = r["binding"]
             return r
 
-        kernels = [roof("march", "rt_march_kernel", march_ms), roof("freq", "rt_freq_kernel", freq_ms)]
+        if fused:
+            # ONE launch runs the whole path (rt_fused.hip: march and frequency pass as two phases of the same persistent
+            # waves): its algorithmic bytes are the path's, 16 R + C_step S + 4 K 3 L R
+            kernels = [roof("path", "rt_fused_kernel", march_ms + freq_ms)]
+            kernels[0]["achieved_basis"] = ("algorithmic bytes of the contract formula for the whole path "
+                                            "(16 R + C_step S + 4 K 3 L R): one launch marches and integrates; not HBM traffic")
+        else:
+            kernels = [roof("march", "rt_march_kernel", march_ms), roof("freq", "rt_freq_kernel", freq_ms)]
         dominant = max(kernels, key=lambda r: r["kernel_ms_avg"])
         path_ach = alg["path"] / (kernel_ms * 1e-3) / 1e9
         line = {
@@ -762,6 +771,33 @@ def main() -> int:
                               "algorithmic_bytes": alg["path"],
                               "bytes_per_ray_step": alg["path"] / max(1, stats["cell_steps"])},
         }
+        line["launches_per_step"] = 1 if fused else 2
+        if fused and world == 1 and not args.no_extras:
+            # the same workload as two kernels (RT_HIP_FUSED=2), for the per-kernel figures of earlier rounds: mean of
+            # 8 runs after 2, HIP events on the launch stream
+            try:
+                os.environ["RT_HIP_FUSED"] = "2"
+                with backend.Plan(mine, device=local) as plan2:
+                    plan2.set_ray_grid()
+                    tk = []
+                    for i in range(10):
+                        plan2.run(stream, image.data_ptr(), iang.data_ptr())
+                        if i >= 2:
+                            tk.append(plan2.kernel_times())
+                m2 = float(np.mean([t[0] for t in tk]))
+                f2 = float(np.mean([t[1] for t in tk]))
+                line["roofline_two_kernel"] = {
+                    "what": "the same step as two launches (RT_HIP_FUSED=2): march kernel, records in HBM / L2, frequency kernel",
+                    "runs": len(tk), "kernel_ms_sum": m2 + f2, "one_launch_speedup": (m2 + f2) / kernel_ms,
+                    "march": {"kernel": "rt_march_kernel", "kernel_ms_avg": m2, "algorithmic_bytes_per_launch": alg["march"],
+                              "frac": alg["march"] / (m2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "freq": {"kernel": "rt_freq_kernel", "kernel_ms_avg": f2, "algorithmic_bytes_per_launch": alg["freq"],
+                             "frac": alg["freq"] / (f2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "path_frac": alg["path"] / ((m2 + f2) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            except Exception as exc:  # noqa: BLE001
+                line["roofline_two_kernel"] = {"error": repr(exc)}
+            finally:
+                os.environ.pop("RT_HIP_FUSED", None)
         if steady is not None:
             steady["value"] = stats["cell_steps"] / (steady["ms_per_step"] * 1e-3) * (world if scaling == "weak" else 1)
             if world > 1 and scaling == "strong":

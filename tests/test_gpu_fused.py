@@ -1,0 +1,178 @@
+"""The one-launch run (raytrace-miniapp_amd/csrc/rt_fused.hip: march and frequency pass as two phases of the same
+persistent waves) against the oracle and against the two-kernel run of the same plan.
+
+It is taken by itself for the emission mode on the beam's own ray grid (what RayTrace::create_image builds for an
+ASE file, src/RayTraceImage.cpp:283-328) when the frequency pass fits into LDS beside the march tables;
+RT_HIP_FUSED=2 keeps the two kernels.  Both must give the CPU loop's image (RayTraceImageCPU.cpp:19-70)."""
+import copy
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+rt = importlib.import_module("raytrace-miniapp_amd")
+problem_mod = importlib.import_module("raytrace-miniapp_amd.problem")
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-7   # one float rounding of es/gs per sub-segment (frequency kernel)
+
+
+def run_grid(hip, p, fused, **grid):
+    os.environ["RT_HIP_FUSED"] = "1" if fused else "2"
+    try:
+        with hip.Plan(p) as plan:
+            plan.set_ray_grid(**grid)
+            out = plan.run().fetch()
+            out["fused"] = plan.last_fused()
+    finally:
+        os.environ.pop("RT_HIP_FUSED", None)
+    return out
+
+
+def same_images(a, b, tol=1e-13):
+    """Two device runs of one problem: the deposit order of the atomics differs, nothing else."""
+    assert rel_l2(a["image"], b["image"]) < tol and rel_l2(a["I_ang"], b["I_ang"]) < tol
+    for key in ("n_rays", "cell_steps", "n_escaped", "n_skipped"):
+        assert a["stats"][key] == b["stats"][key], key
+    assert a["failure_code"] == b["failure_code"]
+
+
+def test_one_launch_run_of_the_shipped_file_equals_the_reference_and_the_two_kernel_run(hip, ase_small, ase_ref):
+    one, two = run_grid(hip, ase_small, True), run_grid(hip, ase_small, False)
+    assert one["fused"] and not two["fused"]
+    assert one["stats"]["n_rays"] == 399000 and one["stats"]["cell_steps"] == 4768067
+    assert rel_l2(one["image"], ase_ref["image"]) < TIGHT and rel_l2(one["I_ang"], ase_ref["I_ang"]) < TIGHT
+    same_images(one, two)
+    # the default (no environment) is the one-launch run
+    with hip.Plan(ase_small) as plan:
+        plan.set_ray_grid().run()
+        assert plan.last_fused()
+        m, f = plan.kernel_times()
+        assert m > 0 and f < 0.05 * m          # one launch: the whole time is on the first event pair
+
+
+@pytest.mark.parametrize("scale", [0.25, 2.0, 16.0])
+def test_one_launch_run_on_scaled_problems_takes_every_work_group_size(hip, oracle, ase_small, scale):
+    """scale_problem (the reference's own enlargement rule, CreateImageHelpers.cpp:104-150): 0.25 -> 512-thread
+    work-groups with every transposition buffer beside the tables, 2 -> 768, 16 (the ASE_medium stand-in) -> 1024
+    threads, four waves with buffers that overlay the march tables."""
+    p = rt.scale_problem(ase_small, scale)
+    if p.beam.na * p.beam.nb < 32:
+        pytest.skip("fewer than 32 rays per pixel: the run keeps two kernels")
+    one, two = run_grid(hip, p, True), run_grid(hip, p, False)
+    assert one["fused"] and not two["fused"]
+    same_images(one, two)
+    if scale <= 2.0:
+        ref = oracle.image_loop(p, p.build_rays())
+        assert one["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+        assert rel_l2(one["image"], ref["image"]) < TIGHT and rel_l2(one["I_ang"], ref["I_ang"]) < TIGHT
+
+
+def test_one_launch_run_with_ragged_ray_ranges_and_strides(hip, oracle, ase_small):
+    """Sub-ranges of the ray grid (N_start / N_parallel, RayTraceImage.cpp:300-313): a last tile with fewer than 64
+    rays, fewer tiles than waves, a single ray."""
+    total = ase_small.n_rays_total
+    for first, stride, count in [(0, 1, 64 * 1000 + 17), (5, 3, 40000), (0, 1, 1), (123, 1, 63), (0, 7, total // 7)]:
+        one = run_grid(hip, ase_small, True, first=first, stride=stride, count=count)
+        two = run_grid(hip, ase_small, False, first=first, stride=stride, count=count)
+        assert one["fused"] and one["stats"]["n_rays"] == count
+        same_images(one, two)
+        ids = first + stride * np.arange(count, dtype=np.int64)
+        ref = oracle.image_loop(ase_small, ase_small.build_rays(ids))
+        assert one["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+        assert rel_l2(one["image"], ref["image"]) < TIGHT and rel_l2(one["I_ang"], ref["I_ang"]) < TIGHT
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_one_launch_run_for_other_numbers_of_lengths(hip, oracle, ase_small, N):
+    """N != 3: the generic instance of the frequency pass (any number of sub-segments) inside the one launch, as long
+    as the tables leave room for it."""
+    p = copy.copy(ase_small)
+    g = ase_small.gain
+    p.gain = [g[0]] + [g[1 + (i % 2)] for i in range(N - 1)]   # (N follows the number of tables)
+    one, two = run_grid(hip, p, True), run_grid(hip, p, False)
+    # (N = 4: three lengths of tables fill the LDS, no room for the frequency pass beside them -- two kernels)
+    assert one["fused"] == (N == 2) and not two["fused"]
+    same_images(one, two)
+    ref = oracle.image_loop(p, p.build_rays())
+    assert rel_l2(one["image"], ref["image"]) < TIGHT and rel_l2(one["I_ang"], ref["I_ang"]) < TIGHT
+
+
+def test_one_launch_run_reports_failing_rays_like_the_cpu_loop(hip, oracle, ase_small):
+    """Error -3 / -2 (Helper.h:582-594) found by the frequency phase: the run is repeated on the march records
+    (checking pass + deposit without the failing rays) by the stand-alone frequency kernel."""
+    from test_gpu_edges import same_outputs_in_a_failing_run
+    p = copy.copy(ase_small)
+    g = ase_small.gain[2]
+    gv = g.gv.copy()
+    gv[::7] = np.nan
+    p.gain = ase_small.gain[:2] + [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv)]
+    one = run_grid(hip, p, True)
+    ref = oracle.image_loop(p, p.build_rays())
+    assert one["fused"]
+    assert ref["failure_code"] & (1 << 3) and one["failure_code"] == ref["failure_code"]
+    same_outputs_in_a_failing_run(one, ref)
+    gv = -np.abs(g.gv)
+    p.gain = ase_small.gain[:2] + [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv)]
+    one = run_grid(hip, p, True)
+    ref = oracle.image_loop(p, p.build_rays())
+    assert ref["failure_code"] & (1 << 2) and one["failure_code"] == ref["failure_code"]
+    same_outputs_in_a_failing_run(one, ref)
+
+
+def test_what_keeps_the_two_kernels(hip, ase_small, seed_small):
+    """Probe, path tracer, seeded mode, ray lists, fewer than 32 rays per pixel: the two-kernel run, whatever the
+    environment says."""
+    os.environ["RT_HIP_FUSED"] = "1"
+    try:
+        with hip.Plan(ase_small) as plan:
+            plan.set_ray_grid().enable_probe().run()
+            assert not plan.last_fused()
+        with hip.Plan(ase_small) as plan:
+            plan.set_rays(ase_small.build_rays(np.arange(0, 64 * 500, dtype=np.int64))).run()
+            assert not plan.last_fused()
+        with hip.Plan(seed_small) as plan:
+            plan.set_ray_grid(count=64 * 2000).run()
+            assert not plan.last_fused()
+        few = problem_mod.regrid_beam(ase_small, na=4, nb=4)
+        with hip.Plan(few) as plan:
+            plan.set_ray_grid().run()
+            assert not plan.last_fused()
+    finally:
+        os.environ.pop("RT_HIP_FUSED", None)
+
+
+def test_exact_emission_mode_inside_the_one_launch(hip, oracle, ase_small):
+    os.environ["RT_HIP_FUSED"] = "1"
+    try:
+        with hip.Plan(ase_small) as plan:
+            plan.set_ray_grid(count=64 * 900 + 5).set_exact_emission().run()
+            out = plan.fetch()
+            assert plan.last_fused()
+    finally:
+        os.environ.pop("RT_HIP_FUSED", None)
+    ref = oracle.image_loop(ase_small, ase_small.build_rays(np.arange(64 * 900 + 5, dtype=np.int64)))
+    assert rel_l2(out["image"], ref["image"]) < 1e-11 and rel_l2(out["I_ang"], ref["I_ang"]) < 1e-11
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_grids_through_the_one_launch_run(hip, oracle, ase_small, seed):
+    """Random ray-grid sizes and frequency counts (rows padded to four frequencies, windows of 64): one launch
+    against the two kernels and, for the smaller ones, the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    na, nb = int(rng.integers(6, 24)), int(rng.integers(6, 24))
+    nx, ny = int(rng.integers(3, 40)), int(rng.integers(2, 20))
+    p = problem_mod.regrid_beam(ase_small, nx=nx, ny=ny, na=na, nb=nb)
+    if rng.random() < 0.5:
+        p = problem_mod.resample_frequency(p, int(rng.integers(5, 150)))
+    if na * nb < 32:
+        pytest.skip("fewer than 32 rays per pixel")
+    one, two = run_grid(hip, p, True), run_grid(hip, p, False)
+    assert one["fused"] and not two["fused"]
+    same_images(one, two, tol=1e-12)
+    if p.n_rays_total <= 400000:
+        ref = oracle.image_loop(p, p.build_rays())
+        assert one["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+        assert rel_l2(one["image"], ref["image"]) < TIGHT and rel_l2(one["I_ang"], ref["I_ang"]) < TIGHT

@@ -7,8 +7,12 @@ be = importlib.import_module("raytrace-miniapp_amd.backend")
 var, vals = sys.argv[1], sys.argv[2:]
 case = os.environ.get("RT_CASE", "ase")
 base = rt.datfile.load('tests/golden/ASE_small.dat.xz')
-p = {"ase": lambda: rt.scale_problem(base, 16.0), "small": lambda: base,
-     "seed": lambda: rt.datfile.load('tests/golden/seed_small.dat.xz')}[case]()
+mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
+if case.startswith("shard"):   # rank-0 pixel-column shard of an N-rank run of the stand-in
+    p = mg.shard(rt.scale_problem(base, 16.0), 0, int(case[5:]))
+else:
+    p = {"ase": lambda: rt.scale_problem(base, 16.0), "small": lambda: base,
+         "seed": lambda: rt.datfile.load('tests/golden/seed_small.dat.xz')}[case]()
 best = {v: (1e9, 1e9) for v in vals}
 with be.Plan(p) as plan:
     plan.set_ray_grid()
