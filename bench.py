@@ -99,7 +99,7 @@ def committed_counters() -> dict:
     """Counter passes are separate rocprofv3 runs (MI355X_MICROARCH.md); their summary is committed
     under profiles/ and quoted here with its source, the commit it was taken at and the hash of the kernel
     sources it was taken on.  Counters of other kernel sources are NOT quoted: {"_stale": ...}."""
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             try:

@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-KERNELS = ("rt_march_kernel", "rt_freq_kernel")
+KERNELS = ("rt_fused_kernel", "rt_march_kernel", "rt_freq_kernel")
 
 
 def find(root, pattern):
@@ -133,6 +133,10 @@ def main():
             clocks.append(gui / 8.0 / (kt[k]["avg_ns"] * 1e-9))
     if clocks:
         out["shader_clock_hz"] = sum(clocks) / len(clocks)
+    # the same step as two launches (RT_HIP_FUSED=2): kernel-trace pass and SQ pass, for the per-kernel figures
+    t2 = kernel_stats(root, here / f"{tag}_two_kernel_kernel_stats.csv", "trace2")
+    if t2:
+        out["two_kernel"] = {"kernel_trace": t2, "pmc_sq": pmc(root, "pmc_sq_2k")}
     # BASELINE config 5 and the seeded half of config 3 (bench.py --workload config5 / seed_medium)
     for prefix, name in (("c5", "config5"), ("sm", "seed_medium")):
         rec = workload_traffic(root, here, tag, prefix, name)

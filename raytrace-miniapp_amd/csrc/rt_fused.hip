@@ -84,6 +84,10 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
 
     // ---- phase 2: this wave's rays have run out; frequency pass on the work-group's finished tiles ----
     const int lane = lane_id();
+#ifdef RT_WAVETIMES // diagnostic build: {left the march, has a buffer, first tile done, end, where, tiles} per wave in g_ft
+    const unsigned long long fu_left = __builtin_amdgcn_s_memrealtime();
+    unsigned long long fu_first = 0, fu_tiles = 0;
+#endif
     unsigned slot  = 0;
     if (lane == 0) {
         __hip_atomic_fetch_add(&ctl[1], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // one marching wave less
@@ -105,6 +109,9 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     }
     double *xpose = mine;
     double *cache = mine + FREQ_WAVE_XPOSE;
+#ifdef RT_WAVETIMES
+    const unsigned long long fu_buf = __builtin_amdgcn_s_memrealtime();
+#endif
     for (;;) {
         unsigned tile = TILE_NONE;
         if (lane == 0)
@@ -133,7 +140,26 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         int lane_t      = lane;
         asm volatile("" : "+s"(hflags), "+v"(lane_t));
         freq_tile<SF, true>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
+#ifdef RT_WAVETIMES
+        if (!fu_first)
+            fu_first = __builtin_amdgcn_s_memrealtime();
+        fu_tiles++;
+#endif
     }
+#ifdef RT_WAVETIMES
+    if (lane == 0) {
+        const unsigned long long fu_end = __builtin_amdgcn_s_memrealtime();
+        const unsigned w = atomicAdd(&g_ft_n, 1u);
+        if (w < 8192) {
+            g_ft[0][w] = fu_left;
+            g_ft[1][w] = fu_buf;
+            g_ft[2][w] = fu_first ? fu_first : fu_end;
+            g_ft[3][w] = fu_end;
+            g_ft[4][w] = (unsigned long long) blockIdx.x | ((unsigned long long) (threadIdx.x >> 6) << 16) | ((unsigned long long) slot << 24);
+            g_ft[5][w] = fu_tiles;
+        }
+    }
+#endif
     __syncthreads();
     if (!(H.flags & FQ_DBG_NOFLUSH)) {
         for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x) {
