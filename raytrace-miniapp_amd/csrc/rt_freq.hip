@@ -351,7 +351,77 @@ template <typename T> __device__ __forceinline__ T load_cold(const RT_CONST_AS T
     return r;
 }
 
-template <int SF, bool EMIS>
+// Where a ray deposits and what it starts with -- the per-ray part of the frequency pass that does not depend on
+// the frequency (Helper.h:518-533, RayTraceImageCPU.cpp:37-54): exit angles, seed factor, the four deposit cells.
+// (Round 4 ran it for every ray of a launch in a pass of its own before the frequency kernel, result left in the
+// record: seed_small 1.446 against 1.222 ms -- the pass re-reads and re-writes every line of the 750 MB of records,
+// which costs more than the chain of loads it takes out of the tile preamble, where four waves per SIMD cover it.)
+struct Placed {
+    double f0; // seed factor (0 without a seed, for escaped rays and outside the profile)
+    int pix;   // pixel i + j nx, or -1
+    int ang;   // angle cell k + m na, or -1
+};
+__device__ __forceinline__ Placed place_ray(const unsigned hflags, ColdPtr C, const DevRays &R, const int nx, const bool backward,
+                                            const unsigned ridx, const RecMeta &m, const unsigned fl, const rt_ray &ray)
+{
+    Placed P   = { 0.0, -1, -1 };
+    rt_ray out = ray;
+    rt_ray r2  = { m.px, m.py, 0.0f, 0.0f };
+    if (hflags & FQ_NEED_EXIT) {
+        // Helper.h:518-521: atanf(s.x / s.z) * 1e3f
+        r2.a = atanf_flt32_kernel(m.sx / m.sz) * 1e3f;
+        r2.b = atanf_flt32_kernel(m.sy / m.sz) * 1e3f;
+    }
+    if ((hflags & FQ_HAS_SEED) && !(fl & F_ESCAPED)) { // Helper.h:523-533
+        if (backward || !R.sf) {
+            const DevSeed SD = load_cold(&C->seed);
+            P.f0 = backward ? seed_factor(SD, (double) m.px, (double) m.py, (double) r2.a, (double) r2.b)
+                            : seed_factor(SD, (double) ray.x, (double) ray.y, (double) ray.a, (double) ray.b);
+        } else {
+            // the launch ray is a grid point: product of the tabulated factors, in seed_factor's order
+            unsigned gi, gj, gk, gm;
+            grid_index(R, ridx, gi, gj, gk, gm);
+            const unsigned oj = (unsigned) R.ngx, ok = oj + (unsigned) R.ngy, om = ok + (unsigned) R.nga;
+            if (R.sin[gi] & R.sin[oj + gj] & R.sin[ok + gk] & R.sin[om + gm]) {
+                P.f0 = C->seed.f0 * R.sf[gi] * R.sf[oj + gj] * R.sf[ok + gk] * R.sf[om + gm];
+                P.f0 = P.f0 < 0.0 ? 0.0 : P.f0;
+            }
+        }
+    }
+    if (hflags & FQ_PROBE)
+        C->probe.ray2[ridx] = r2;
+    if (hflags & FQ_OWN_CELLS) {
+        unsigned gi, gj, gk, gm;
+        grid_index(R, ridx, gi, gj, gk, gm);
+        P.pix = (int) (gi + gj * (unsigned) nx);
+        P.ang = (int) (gk + gm * (unsigned) R.nga);
+    } else {
+        if (!backward) { // RayTraceImageCPU.cpp:37-49
+            out   = r2;
+            out.a = -out.a;
+            out.b = -out.b;
+            if ((double) out.y < 0.0 && C->beam.g_first[1] >= 0.0)
+                out.y = -out.y;
+        }
+        const AxisIn A[4] = {
+            { C->beam.nx, C->beam.x, C->beam.dx, C->beam.inv_dx, C->beam.g_first[0], C->beam.g_last[0], (double) out.x },
+            { C->beam.ny, C->beam.y, C->beam.dy, C->beam.inv_dy, C->beam.g_first[1], C->beam.g_last[1], (double) out.y },
+            { C->beam.na, C->beam.a, C->beam.da, C->beam.inv_da, C->beam.g_first[2], C->beam.g_last[2], (double) out.a },
+            { C->beam.nb, C->beam.b, C->beam.db, C->beam.inv_db, C->beam.g_first[3], C->beam.g_last[3], (double) out.b } };
+        int ix[4];
+        deposit_index4(A, ix);
+        if (ix[0] >= 0 && ix[1] >= 0)
+            P.pix = ix[0] + ix[1] * nx;
+        if (ix[2] >= 0 && ix[3] >= 0)
+            P.ang = ix[2] + ix[3] * C->beam.na;
+    }
+    return P;
+}
+
+// MAXQ: pixel runs of a tile that the few-runs deposit takes (its window totals are [MAXQ][64] doubles of the wave's
+// LDS scratch): 3 in the stand-alone kernel, 2 in the one-launch run where LDS is short and a tile spans two pixels
+// at most (rt_fused.hip)
+template <int SF, bool EMIS, int MAXQ = FREQ_MAXQ>
 __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflags, ColdPtr C, double *lds_iang, const double *tab,
                                           double *xpose, double *cache, const unsigned tile, const int lane)
 {
@@ -411,59 +481,13 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         return r;
     };
     bool err1   = have && (double) (m.sz * m.sz) < 0.01; // Helper.h:515
-    rt_ray out  = ray;
     double f0   = 0.0;
     int pix = -1, ang = -1;
     if (have && !err1) {
-        rt_ray r2 = { m.px, m.py, 0.0f, 0.0f };
-        if (hflags & FQ_NEED_EXIT) {
-            // Helper.h:518-521: atanf(s.x / s.z) * 1e3f
-            r2.a = atanf_flt32_kernel(m.sx / m.sz) * 1e3f;
-            r2.b = atanf_flt32_kernel(m.sy / m.sz) * 1e3f;
-        }
-        if ((hflags & FQ_HAS_SEED) && !(fl & F_ESCAPED)) { // Helper.h:523-533
-            if (backward || !R.sf) {
-                const DevSeed SD = load_cold(&C->seed);
-                f0 = backward ? seed_factor(SD, (double) m.px, (double) m.py, (double) r2.a, (double) r2.b)
-                              : seed_factor(SD, (double) ray.x, (double) ray.y, (double) ray.a, (double) ray.b);
-            } else {
-                // the launch ray is a grid point: product of the tabulated factors, in seed_factor's order
-                unsigned gi, gj, gk, gm;
-                grid_index(R, ridx, gi, gj, gk, gm);
-                const unsigned oj = (unsigned) R.ngx, ok = oj + (unsigned) R.ngy, om = ok + (unsigned) R.nga;
-                if (R.sin[gi] & R.sin[oj + gj] & R.sin[ok + gk] & R.sin[om + gm]) {
-                    f0 = C->seed.f0 * R.sf[gi] * R.sf[oj + gj] * R.sf[ok + gk] * R.sf[om + gm];
-                    f0 = f0 < 0.0 ? 0.0 : f0;
-                }
-            }
-        }
-        if (probe_on)
-            C->probe.ray2[ridx] = r2;
-        if (own) {
-            unsigned gi, gj, gk, gm;
-            grid_index(R, ridx, gi, gj, gk, gm);
-            pix = (int) (gi + gj * (unsigned) H.nx);
-            ang = (int) (gk + gm * (unsigned) R.nga);
-        } else {
-            if (!backward) { // RayTraceImageCPU.cpp:37-49
-                out   = r2;
-                out.a = -out.a;
-                out.b = -out.b;
-                if ((double) out.y < 0.0 && C->beam.g_first[1] >= 0.0)
-                    out.y = -out.y;
-            }
-            const AxisIn A[4] = {
-                { C->beam.nx, C->beam.x, C->beam.dx, C->beam.inv_dx, C->beam.g_first[0], C->beam.g_last[0], (double) out.x },
-                { C->beam.ny, C->beam.y, C->beam.dy, C->beam.inv_dy, C->beam.g_first[1], C->beam.g_last[1], (double) out.y },
-                { C->beam.na, C->beam.a, C->beam.da, C->beam.inv_da, C->beam.g_first[2], C->beam.g_last[2], (double) out.a },
-                { C->beam.nb, C->beam.b, C->beam.db, C->beam.inv_db, C->beam.g_first[3], C->beam.g_last[3], (double) out.b } };
-            int ix[4];
-            deposit_index4(A, ix);
-            if (ix[0] >= 0 && ix[1] >= 0)
-                pix = ix[0] + ix[1] * H.nx;
-            if (ix[2] >= 0 && ix[3] >= 0)
-                ang = ix[2] + ix[3] * C->beam.na;
-        }
+        const Placed P = place_ray(hflags, C, R, H.nx, backward, ridx, m, fl, ray);
+        f0  = P.f0;
+        pix = P.pix;
+        ang = P.ang;
     }
     if (have && probe_on) {
         C->probe.flags[ridx] = fl | (err1 ? F_ERR1 : 0u);
@@ -500,7 +524,6 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     // atomics, rows are flushed per tile with coalesced atomics.  More distinct pixels than
     // rows: a segmented shuffle scan over the runs (adding the lanes of the surplus pixels
     // to the image one by one was tried: twice as slow on the 124.8 M-ray seeded case).
-    constexpr int MAXQ               = FREQ_MAXQ;
     const int pix_before             = __shfl_up(pix, 1, WAVE);
     const unsigned long long head_m  = __ballot(lane == 0 || pix_before != pix);
     const int n_runs                 = (int) __popcll(head_m);

@@ -50,7 +50,11 @@ struct FusedKArg {
     FusedLay lay;
 };
 
-template <bool BOUNDED, int SF>
+// MAXQ: pixel runs per tile of the few-runs deposit (2 when a pixel has at least 64 rays: a transposition buffer is
+// then 3.1 KB instead of 3.6 and fifteen of sixteen fit beside the tables of the shipped grids, so that only the last
+// wave of a work-group to leave the march -- which waits for nobody -- takes an overlaid one)
+constexpr int fused_wave_doubles(int maxq) { return 4 * XP_ROW + maxq * WAVE; }
+template <bool BOUNDED, int SF, int MAXQ>
 __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         __builtin_amdgcn_wave_barrier();
     }
     double *xpose = mine;
-    double *cache = mine + FREQ_WAVE_XPOSE;
+    double *cache = mine + fused_wave_doubles(MAXQ); // (no row cache in this kernel: nslot = 0)
 #ifdef RT_WAVETIMES
     const unsigned long long fu_buf = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         unsigned hflags = H.flags;
         int lane_t      = lane;
         asm volatile("" : "+s"(hflags), "+v"(lane_t));
-        freq_tile<SF, true>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
+        freq_tile<SF, true, MAXQ>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
 #ifdef RT_WAVETIMES
         if (!fu_first)
             fu_first = __builtin_amdgcn_s_memrealtime();

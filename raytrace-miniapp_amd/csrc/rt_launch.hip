@@ -322,7 +322,10 @@ int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         !p->P.exclusive && p->P.safe == 0 && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32 &&
         p->n_iang * sizeof(double) <= 32 * 1024 && env_unsigned("RT_HIP_FUSED", 1, 1, 2) == 1) {
         const unsigned nw       = bthr / 64;
-        const size_t per_wave   = (size_t) rt::FREQ_WAVE_XPOSE; // doubles: transposition rows + window totals, no row cache
+        // doubles per wave: transposition rows + window totals of the few-runs deposit for 2 pixel runs per tile (a pixel
+        // has at least 64 rays) or 3, no row cache
+        const int maxq          = p->P.rays.nga * p->P.rays.ngb >= 64 ? 2 : 3;
+        const size_t per_wave   = (size_t) rt::fused_wave_doubles(maxq);
         rt::FusedLay lay;
         lay.off_exp  = (unsigned) align_up(p->P.blob_bytes, 16);
         lay.off_iang = lay.off_exp + 2u * rt::EXP_TAB * (unsigned) sizeof(double);
@@ -358,8 +361,11 @@ int plan_run_split(rt_hip_plan *p, hipStream_t stream)
             fa.lay       = lay;
             const int S  = p->P.L * RT_N_SUB;
             using fused_fn = void (*)(const rt::FusedKArg);
-            const fused_fn fk = S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6> : rt::rt_fused_kernel<false, 6>)
-                                       : (bounded ? rt::rt_fused_kernel<true, 0> : rt::rt_fused_kernel<false, 0>);
+            const fused_fn fk =
+                maxq == 2 ? (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 2> : rt::rt_fused_kernel<false, 6, 2>)
+                                    : (bounded ? rt::rt_fused_kernel<true, 0, 2> : rt::rt_fused_kernel<false, 0, 2>))
+                          : (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 3> : rt::rt_fused_kernel<false, 6, 3>)
+                                    : (bounded ? rt::rt_fused_kernel<true, 0, 3> : rt::rt_fused_kernel<false, 0, 3>));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int) flds));
             unsigned long long fwant = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
             const unsigned fgrid     = (unsigned) (fwant < (unsigned long long) p->cu_count ? fwant : (unsigned long long) p->cu_count);
