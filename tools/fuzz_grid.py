@@ -16,6 +16,7 @@ a = rt.datfile.load('tests/golden/ASE_small.dat.xz'); s = rt.datfile.load('tests
 ora = Oracle()
 first, last = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
+n_fused = 0   # cases that took the one-launch run (rt_fused.hip)
 worst = {False: 0.0, True: 0.0}
 for seed in range(first, last):
     rng = np.random.default_rng(77000 + seed)
@@ -26,6 +27,7 @@ for seed in range(first, last):
     outs = {}
     with be.Plan(p) as plan:
         outs["plan"] = plan.set_ray_grid().run().fetch()
+        n_fused += plan.last_fused()
     if seed % 3 == 0:
         outs["image_loop"] = be.image_loop(p, rays)
     if (seed - first) % 2000 == 1999:
@@ -37,4 +39,5 @@ for seed in range(first, last):
             bad += 1
             print("MISMATCH seed", seed, how, "seeded", seeded, "N", p.N, "K", p.beam.nv, n, "rays", len(rays), "err", err,
                   "codes", out["failure_code"], ref["failure_code"], flush=True)
+print(f"one-launch runs: {n_fused} of {last - first} plans")
 print(f"cases {last - first}, mismatches {bad}, worst image / I_ang rel-L2: emission {worst[False]:.2e}, seeded {worst[True]:.2e}")
