@@ -206,3 +206,38 @@ def test_magic_number_division_of_ray_numbers_is_exact():
         for x in xs:
             if 0 <= x < (1 << 31):
                 assert ((x * mul) >> 32) >> sh == x // d, (d, x)
+
+
+def test_cpu_baseline_uses_every_hardware_thread_of_the_affinity_mask(ase_small):
+    """bench.py `cpu_baseline`: the reference's `threads` method takes std::thread::hardware_concurrency() threads
+    (src/RayTraceImage.cpp:409-413); the baseline takes the affinity mask of this process, one pinned thread each,
+    and times the unmodified reference loop (kind "reference") when oracle/_ref travelled, else the port."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    info = bench.cpu_info()
+    want = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    assert info["available"] == want == len(info["cpus"]) and 1 <= len(info["physical_cpus"]) <= want
+    before = sorted(os.sched_getaffinity(0))
+    rec = bench.cpu_baseline(ase_small, 4768067)
+    assert sorted(os.sched_getaffinity(0)) == before, "the main thread's affinity is restored"
+    assert rec["cores"] in (want, len(info["physical_cpus"])) and rec["all_hardware_threads"]["threads"] == want
+    assert rec["kind"] in ("reference", "port") and rec["value"] > 0 and rec["one_core"]["value"] > 0
+    assert rec["value"] >= 0.8 * rec["one_core"]["value"]          # more threads are not slower than one
+    assert "round-robin" in rec["sample"] and "pinned" in rec["sample"]
+
+
+def test_bench_accounting_of_the_contract_formula():
+    """B_read = 16 R + C_step S + 4 K 3 L R [+ (256 + 8 K) R_live]; the ASE_small figures of the
+    survey (962 MB) must come out of bench.algorithmic_bytes."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    a = bench.algorithmic_bytes(399000, 4768067, 2, 52, False, 0, 60 * 25, 19 * 14)
+    assert a["march"] == 16 * 399000 + 96 * 4768067 and a["freq"] == 4 * 52 * 3 * 2 * 399000
+    assert abs(a["path"] - 962e6) < 1e6 and a["write"] == 8 * (60 * 25 * 52 + 19 * 14)
+    s = bench.algorithmic_bytes(7803000, 53573880, 2, 82, True, 6907454, 1500, 266)
+    assert abs(s["path"] - 26.1e9) < 0.5e9
