@@ -49,6 +49,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD = 1024          # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+KERNEL_SOURCES = ("rt_device.h", "rt_freq.hip", "rt_fused.hip", "rt_march.hip", "rt_math.h", "rt_path.hip")
 
 
 # --------------------------------------------------------------------------- self-launch
@@ -83,15 +84,16 @@ def algorithmic_bytes(n_rays: int, cell_steps: int, L: int, K: int, seeded: bool
 
 
 def kernel_source_hash() -> str:
-    """sha1 over the kernel sources (csrc/*.hip, *.h): profiles/summarize.py stamps the committed counter
-    summary with it, and the counters are quoted only while the kernels are the ones they were measured on."""
+    """sha1 over the kernel sources (the device code: KERNEL_SOURCES below, not the host translation units):
+    profiles/summarize.py stamps the committed counter summary with it, and the counters are quoted only while the
+    kernels are the ones they were measured on."""
     import hashlib
 
     h = hashlib.sha1()
     csrc = ROOT / "raytrace-miniapp_amd" / "csrc"
-    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
-        h.update(f.name.encode())
-        h.update(f.read_bytes())
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update((csrc / name).read_bytes())
     return h.hexdigest()[:16]
 
 

@@ -68,15 +68,15 @@ def pmc(root, sub):
 
 
 def kernel_source_hash():
-    """The same hash bench.py computes: sha1 over csrc/*.hip and *.h (bench.py quotes these counters only while
-    the kernel sources are the ones they were measured on)."""
+    """The same hash bench.py computes: sha1 over the device code (bench.py quotes these counters only while the
+    kernel sources are the ones they were measured on)."""
     import hashlib
 
     h = hashlib.sha1()
     csrc = Path(__file__).resolve().parent.parent / "raytrace-miniapp_amd" / "csrc"
-    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
-        h.update(f.name.encode())
-        h.update(f.read_bytes())
+    for name in ("rt_device.h", "rt_freq.hip", "rt_fused.hip", "rt_march.hip", "rt_math.h", "rt_path.hip"):
+        h.update(name.encode())
+        h.update((csrc / name).read_bytes())
     return h.hexdigest()[:16]
 
 

@@ -61,6 +61,18 @@ def test_image_loop_recognises_the_grid_and_survives_a_list_that_only_looks_like
     assert c["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
     assert rel_l2(c["image"], ref["image"]) < 1e-6 and rel_l2(c["I_ang"], ref["I_ang"]) < 1e-6
     assert rel_l2(c["image"], a["image"]) > 0
+    # the all-devices entry speculates likewise (devices start tracing the guessed grid while the list is verified, the
+    # verdict arrives before the collective): the look-alike list ends the first attempt and is traced as ray chunks,
+    # on the degenerate communicator and on the three-worker rehearsal
+    for loop in ("", "3"):
+        if loop:
+            monkeypatch.setenv("RT_HIP_MULTI_LOOPBACK", loop)
+        d = hip.multi_image_loop(ase_small, odd)
+        assert d["mode"] == 2 and d["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
+        assert rel_l2(d["image"], ref["image"]) < 1e-6 and rel_l2(d["I_ang"], ref["I_ang"]) < 1e-6
+        e = hip.multi_image_loop(ase_small, rays)
+        assert e["mode"] == 1 and rel_l2(e["image"], a["image"]) < 1e-12
+    monkeypatch.delenv("RT_HIP_MULTI_LOOPBACK")
 
 
 def test_pool_trim_and_concurrent_image_loops(hip, ase_small):
