@@ -84,6 +84,9 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     const TileList list{ &ctl[0], A.tile_next, reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + (threadIdx.x >> 6) * 32u };
 
     // ---- phase 1: the march (rt_march.hip), one tile per chunk, finished tiles pushed onto the list ----
+    // (marching waves given a higher wave priority than the waves of their SIMD that have turned to the frequency pass
+    // -- so that the stragglers with the long rays finish sooner: measured, s_setprio 1 and 3, nothing: 2.66 / 2.65
+    // against 2.65 ms, 8-rank shard 0.537 / 0.536 against 0.534; profiles/r04_prio_ab.txt)
     march_wave<true, BOUNDED, true>(A.P, lds_raw, list);
 
     // ---- phase 2: this wave's rays have run out; frequency pass on the work-group's finished tiles ----

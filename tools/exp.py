@@ -19,8 +19,10 @@ libs = [a for a in args if a.endswith(".so")] or [str(be.CSRC / "librt_hip.so")]
 base = rt.datfile.load('tests/golden/ASE_small.dat.xz')
 probs = {"ase": rt.scale_problem(base, 16.0), "seed": rt.datfile.load('tests/golden/seed_small.dat.xz'),
          "small": base}
+mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
 for case in cases.split(","):
-    p = probs[case]
+    # "shardN": the rank-0 pixel-column shard of an N-rank run of the stand-in
+    p = mg.shard(probs["ase"], 0, int(case[5:])) if case.startswith("shard") else probs[case]
     plans = []
     for path in libs:
         plan = be.Plan(p, lib=be.HipLibrary(path))
