@@ -227,8 +227,9 @@ int plan_repeat_checked(rt_hip_plan *p)
     return RT_OK;
 }
 
-// Two-kernel path: march (persistent lanes) -> records in HBM -> frequency pass.
-int plan_run_split(rt_hip_plan *p, hipStream_t stream)
+// One run on a queue: the march (persistent lanes) -> one record per ray -> the frequency pass, as ONE launch
+// (rt_fused.hip) where that applies, as two kernels otherwise (or the path tracer in place of the frequency kernel).
+int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
 {
     const size_t need = (size_t) p->n_rays * p->P.rec_stride;
     if (need > p->rec_bytes || !p->rec) {
@@ -239,9 +240,8 @@ int plan_run_split(rt_hip_plan *p, hipStream_t stream)
         p->rec_bytes = need;
     }
     p->P.rec = p->rec;
-    // march: persistent 256-thread work-groups
-    // LDS variant: the whole march blob in LDS, one 1024-thread work-group per CU;
-    // global variant when the blob does not fit (RT_HIP_MARCH=global forces it)
+    // march, LDS variant: the whole march blob in LDS, one work-group of up to 1024 threads per CU;
+    // global variant (persistent 256-thread work-groups) when the blob does not fit (RT_HIP_MARCH=global forces it)
     const char *force   = getenv("RT_HIP_MARCH");
     const bool lds_tab  = p->P.blob_bytes + 8 * 1024 <= p->lds_limit && !(force && strcmp(force, "global") == 0);
     unsigned bthr = lds_tab ? 1024u : 256u;

@@ -749,7 +749,7 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     }
     p->runs++;
 
-    rc = plan_run_split(p, stream);
+    rc = plan_launch_run(p, stream);
     if (rc != RT_OK)
         return rc;
     p->last_stream = stream;

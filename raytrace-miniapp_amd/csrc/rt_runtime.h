@@ -134,7 +134,7 @@ int tan_mode(int device);
 
 // ---- rt_launch.hip -----------------------------------------------------------------------------------
 // march -> records -> frequency pass (or the path tracer) on `stream`; records ev0 / evm / ev1 of the plan
-int plan_run_split(rt_hip_plan *p, hipStream_t stream);
+int plan_launch_run(rt_hip_plan *p, hipStream_t stream);
 // a run that reported failing rays: repeat the frequency pass without them
 int plan_repeat_checked(rt_hip_plan *p);
 int launch_tan(const rt_ray *rays_dev, unsigned long long n, float *sxy_dev, hipStream_t stream);

@@ -1,5 +1,5 @@
 """March work-group size and rays per counter fetch on pixel-column shards of the stand-in (8, 6 and 16 ranks): the
-data behind the thresholds in plan_run_split (rt_launch.hip)."""
+data behind the thresholds in plan_launch_run (rt_launch.hip)."""
 import importlib, os, sys
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")
