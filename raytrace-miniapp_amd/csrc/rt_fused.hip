@@ -114,6 +114,9 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
             mine[c] = 0.0;
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef RT_ABL_FUSED_MARCH_ONLY // profiling only: what the march phase costs inside this kernel (no frequency phase)
+    return;
+#endif
     double *xpose = mine;
     double *cache = mine + fused_wave_doubles(MAXQ); // (no row cache in this kernel: nslot = 0)
 #ifdef RT_WAVETIMES
