@@ -166,7 +166,35 @@ int launch_freq_any(rt_hip_plan *p, hipStream_t stream, unsigned tile_begin = 0,
 
 } // namespace
 
+namespace rt {
+// the outputs and the control block of a run zeroed by ONE launch (three hipMemsetAsync are three launches with a
+// dependency gap behind each: ~1.5 us apiece, MI355X_MICROARCH.md "boundary" -- a percent of an 8-rank step)
+extern "C" __global__ void __launch_bounds__(256) rt_zero_kernel(unsigned long long *a, unsigned long long na, unsigned long long *b,
+                                                                unsigned long long nb, unsigned long long *c, unsigned long long nc)
+{
+    const unsigned long long step = (unsigned long long) gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nc; i += step) {
+        unsigned long long *q = i < na ? a + i : (i < na + nb ? b + (i - na) : c + (i - na - nb));
+        *q                    = 0ull;
+    }
+}
+} // namespace rt
+
 namespace rtr {
+
+int launch_zero3(hipStream_t stream, void *a, size_t a_bytes, void *b, size_t b_bytes, void *c, size_t c_bytes)
+{
+    // (8-byte words: the image and I_ang are doubles, DevCtl is 8-byte aligned and sized)
+    const unsigned long long na = a ? a_bytes / 8 : 0, nb = b ? b_bytes / 8 : 0, nc = c ? c_bytes / 8 : 0;
+    if (na + nb + nc == 0)
+        return RT_OK;
+    unsigned long long blocks = (na + nb + nc + 255) / 256;
+    blocks                    = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(rt::rt_zero_kernel, dim3((unsigned) blocks), dim3(256), 0, stream, (unsigned long long *) a, na,
+                       (unsigned long long *) b, nb, (unsigned long long *) c, nc);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
 
 int launch_tan(const rt_ray *rays_dev, unsigned long long n, float *sxy_dev, hipStream_t stream)
 {

@@ -734,10 +734,12 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
         return rc;
     if (p->probe_on && p->n_rays)
         HIP_TRY(hipMemsetAsync(p->probe, 0, (size_t) p->n_rays * (sizeof(rt_ray) + 8), stream));
-    if (!p->P.exclusive) // exclusive mode writes every image row exactly once
-        HIP_TRY(hipMemsetAsync(image_dev, 0, p->n_image * sizeof(double), stream));
-    HIP_TRY(hipMemsetAsync(iang_dev, 0, p->n_iang * sizeof(double), stream));
-    HIP_TRY(hipMemsetAsync(p->ctl, 0, sizeof(rt::DevCtl), stream));
+    static_assert(sizeof(rt::DevCtl) % 8 == 0 && alignof(rt::DevCtl) >= 8, "zeroed in 8-byte words");
+    // (exclusive mode writes every image row exactly once: its image is not zeroed)
+    rc = launch_zero3(stream, p->P.exclusive ? nullptr : image_dev, p->n_image * sizeof(double), iang_dev, p->n_iang * sizeof(double),
+                      p->ctl, sizeof(rt::DevCtl));
+    if (rc != RT_OK)
+        return rc;
     p->P.image   = image_dev;
     p->P.iang    = iang_dev;
     p->P.n_tiles = (unsigned) ((p->n_rays + rt::WAVE - 1) / rt::WAVE);

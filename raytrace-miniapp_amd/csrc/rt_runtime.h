@@ -140,5 +140,7 @@ int plan_repeat_checked(rt_hip_plan *p);
 int launch_tan(const rt_ray *rays_dev, unsigned long long n, float *sxy_dev, hipStream_t stream);
 int launch_seed_tab(const rt::DevSeed &sd, const rt::DevRays &R, size_t n_points, double *sf, unsigned char *sin);
 int launch_selftest(unsigned long long *counts_dev);
+// zero up to three device ranges (8-byte multiples; NULL = none) with one launch
+int launch_zero3(hipStream_t stream, void *a, size_t a_bytes, void *b, size_t b_bytes, void *c, size_t c_bytes);
 
 } // namespace rtr
