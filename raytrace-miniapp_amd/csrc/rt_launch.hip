@@ -259,6 +259,9 @@ int plan_repeat_checked(rt_hip_plan *p)
 // (rt_fused.hip) where that applies, as two kernels otherwise (or the path tracer in place of the frequency kernel).
 int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
 {
+    // the kernels index rays with 32 bits and round the ray count up to whole chunks of at most 4096 rays
+    if (p->n_rays > (unsigned long long) MAX_LIST_RAYS)
+        return fail_arg("more than 2^32 - 4096 rays in one run");
     const size_t need = (size_t) p->n_rays * p->P.rec_stride;
     if (need > p->rec_bytes || !p->rec) {
         plan_quiesce(p);
