@@ -15,25 +15,28 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 
 using namespace rtr;
 
 namespace {
 
-// Dynamic LDS above 64 KB has to be allowed per kernel and per device, once.
-template <class Kernel> int allow_lds(Kernel kernel, int device, size_t bytes, size_t limit)
+// Dynamic LDS above 64 KB has to be allowed per kernel and per device; asked for once per (device, kernel), and
+// again only when a launch needs more than the attribute stands at.
+int allow_lds(const void *kernel, int device, size_t bytes, size_t limit)
 {
     static std::mutex mu;
-    static std::vector<size_t> allowed; // per device: the size the attribute stands at
+    static std::map<std::pair<int, const void *>, size_t> allowed; // the size the attribute stands at
+    if (bytes <= 64 * 1024)
+        return RT_OK;
     std::lock_guard<std::mutex> lock(mu);
-    if ((size_t) device >= allowed.size())
-        allowed.resize((size_t) device + 1, 64 * 1024);
-    if (bytes <= allowed[(size_t) device])
+    size_t &have = allowed[{ device, kernel }];
+    if (bytes <= have)
         return RT_OK;
     const size_t want = limit > bytes ? limit : bytes;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) want));
-    allowed[(size_t) device] = want;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) want));
+    have = want;
     return RT_OK;
 }
 
@@ -142,7 +145,7 @@ template <int SF, bool EMIS> int launch_freq(rt_hip_plan *p, hipStream_t stream,
             return fail_arg(msg);
         }
         {
-            const int rc = allow_lds(&rt::rt_freq_kernel<SF, EMIS>, p->device, lds, p->lds_limit);
+            const int rc = allow_lds(reinterpret_cast<const void *>(&rt::rt_freq_kernel<SF, EMIS>), p->device, lds, p->lds_limit);
             if (rc != RT_OK)
                 return rc;
         }
@@ -296,9 +299,16 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     using march_fn = void (*)(const rt::DevParams);
     const march_fn kernel = lds_tab ? (bounded ? rt::rt_march_kernel<true, true> : rt::rt_march_kernel<true, false>)
                                     : (bounded ? rt::rt_march_kernel<false, true> : rt::rt_march_kernel<false, false>);
-    if (lds_tab)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) mlds));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int) bthr, mlds));
+    if (lds_tab) {
+        const int rc = allow_lds(reinterpret_cast<const void *>(kernel), p->device, mlds, p->lds_limit);
+        if (rc != RT_OK)
+            return rc;
+        per_cu = 1; // one work-group per CU: the tables take more than half of the LDS... or the work-group all wave slots
+        if (2 * mlds + 1024 <= p->lds_limit && bthr <= 512)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int) bthr, mlds));
+    } else {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int) bthr, mlds));
+    }
     if (per_cu < 1)
         per_cu = 1;
     unsigned long long want = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
@@ -397,7 +407,11 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
                                     : (bounded ? rt::rt_fused_kernel<true, 0, 2> : rt::rt_fused_kernel<false, 0, 2>))
                           : (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 3> : rt::rt_fused_kernel<false, 6, 3>)
                                     : (bounded ? rt::rt_fused_kernel<true, 0, 3> : rt::rt_fused_kernel<false, 0, 3>));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int) flds));
+            {
+                const int rc = allow_lds(reinterpret_cast<const void *>(fk), p->device, flds, p->lds_limit);
+                if (rc != RT_OK)
+                    return rc;
+            }
             unsigned long long fwant = ((unsigned long long) p->n_rays + bthr - 1) / bthr;
             const unsigned fgrid     = (unsigned) (fwant < (unsigned long long) p->cu_count ? fwant : (unsigned long long) p->cu_count);
             hipLaunchKernelGGL(fk, dim3(fgrid), dim3(bthr), flds, stream, fa);
