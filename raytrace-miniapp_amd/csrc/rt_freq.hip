@@ -421,7 +421,10 @@ __device__ __forceinline__ Placed place_ray(const unsigned hflags, ColdPtr C, co
 // MAXQ: pixel runs of a tile that the few-runs deposit takes (its window totals are [MAXQ][64] doubles of the wave's
 // LDS scratch): 3 in the stand-alone kernel, 2 in the one-launch run where LDS is short and a tile spans two pixels
 // at most (rt_fused.hip)
-template <int SF, bool EMIS, int MAXQ = FREQ_MAXQ>
+// EXCL: the exclusive deposit (one ray per pixel, plain stores: DevParams::exclusive) -- a launch either is exclusive
+// or is not, and as a compile-time parameter the mode's code and registers stay out of the instances that never use it
+// (with a run-time flag the one-launch kernel carried it, and 32 bytes of scratch with it)
+template <int SF, bool EMIS, int MAXQ = FREQ_MAXQ, bool EXCL = false>
 __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflags, ColdPtr C, double *lds_iang, const double *tab,
                                           double *xpose, double *cache, const unsigned tile, const int lane)
 {
@@ -503,7 +506,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     // exclusive mode: this ray is the only contributor of pixel own_pix and must write its
     // whole row (zeros if it contributes nothing); a ray that deposits elsewhere (never the
     // case for a consistent grid) keeps the atomic path for the foreign pixel.
-    const bool excl_all = (hflags & FQ_EXCLUSIVE) != 0;
+    constexpr bool excl_all = EXCL;
     int own_pix = -1;
     if (excl_all && have) {
         const unsigned j = ridx % (unsigned) H.ny, i = ridx / (unsigned) H.ny;
@@ -768,8 +771,32 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         // per instruction; instead the wave stages 16 frequencies of all its rows in LDS
         // (cache = [64][XS_ROW] here) and stores them as 4 rows x 128 contiguous bytes per
         // instruction.
+        // The rule (checked per tile, wave-uniform): a full tile whose 64 rays deposit into their own pixels, the pixels
+        // nx apart (consecutive rays are consecutive in y: no wrap to the next x inside the tile), K a multiple of the
+        // 16 staged frequencies.  The flush is then 16 x (LDS read at a constant offset, one 64-bit add, store) with no
+        // per-row pixel look-up and no range tests -- the general form below costs ~12 instructions per store, a sixth
+        // of the deposit's instructions on the 4096^2 x 512 image.
+        const int own0        = __builtin_amdgcn_readlane(own_pix, 0);
+        const bool regular_tile = __ballot(have && pix == own_pix) == ~0ull && (K & 15) == 0 &&
+                                  __builtin_amdgcn_readlane(own_pix, WAVE - 1) == own0 + (WAVE - 1) * H.nx;
         frequency_loop([&](int kb, double (&v)[VEC]) {
             double *mine = cache + lane * XS_ROW + (kb & 12);
+            if (regular_tile) {
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
+                    mine[j] = v[j];
+                if ((kb & 12) == 12) {
+                    __builtin_amdgcn_wave_barrier();
+                    double *dst         = H.image + ((size_t) (own0 + (lane >> 4) * H.nx) * (size_t) K + (size_t) ((kb & ~15) + (lane & 15)));
+                    const size_t gstep  = (size_t) 4 * (size_t) H.nx * (size_t) K; // four image rows on
+                    const double *src   = cache + (lane >> 4) * XS_ROW + (lane & 15);
+#pragma unroll 4
+                    for (int g = 0; g < WAVE / 4; g++)
+                        dst[(size_t) g * gstep] = src[g * 4 * XS_ROW];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
                 mine[j] = (pix == own_pix) ? v[j] : 0.0;
@@ -925,7 +952,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
 __device__ unsigned long long g_ft[6][8192]; // [4]: blockIdx | wave << 16 | XCC_ID << 24 | CU/SE id << 32, [5]: tiles done
 __device__ unsigned g_ft_n;
 #endif
-template <int SF, bool EMIS>
+template <int SF, bool EMIS, bool EXCL>
 __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED) rt_freq_kernel(const FreqKArg A)
 {
 #ifdef RT_WAVETIMES
@@ -940,7 +967,7 @@ __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const FreqHot &H       = A.hot;
     const bool iang_in_lds = (H.flags & FQ_IANG_LDS) != 0;
-    const bool excl        = (H.flags & FQ_EXCLUSIVE) != 0;
+    constexpr bool excl    = EXCL;
     const int nslot        = H.nslot;
     const int n_ang        = H.n_ang;
     double *exp2_tab       = reinterpret_cast<double *>(lds_raw);
@@ -1021,7 +1048,7 @@ __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_
         unsigned hflags = H.flags;
         int lane_t      = lane;
         asm volatile("" : "+s"(hflags), "+v"(lane_t));
-        freq_tile<SF, EMIS>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
+        freq_tile<SF, EMIS, FREQ_MAXQ, EXCL>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
 #ifdef RT_WAVETIMES
         if (!ft_first)
             ft_first = __builtin_amdgcn_s_memrealtime();

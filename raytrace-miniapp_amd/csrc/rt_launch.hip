@@ -93,7 +93,7 @@ rt::FreqKArg freq_args(const rt_hip_plan *p, bool iang_in_lds, int nslot, unsign
 
 // frequency kernel variants: SF = compile-time number of sub-segments (6 <=> N = 3,
 // the shipped inputs; 0 = any N)
-template <int SF, bool EMIS> int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
+template <int SF, bool EMIS, bool EXCL> int launch_freq(rt_hip_plan *p, hipStream_t stream, unsigned cap_blocks)
 {
     const size_t ang_bytes = p->n_iang * sizeof(double);
     // (one global atomic per ray on na*nb addresses serialises badly: the histogram stays in LDS)
@@ -103,7 +103,7 @@ template <int SF, bool EMIS> int launch_freq(rt_hip_plan *p, hipStream_t stream,
     // into the work-group's share of the 160 KB beside the exponent tables, the I_ang histogram and the per-wave
     // transposition rows (rt_freq.hip: freq_lds_doubles); fewer than 4 rows is not worth having.
     const int waves       = EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED;
-    const bool excl       = p->P.exclusive != 0;
+    constexpr bool excl   = EXCL; // (= p->P.exclusive: launch_freq_any picks the instance)
     // (exclusive mode is bound by its stores: 12 waves per CU run 3.6 % faster than 16 -- tools/config5_ab.py)
     int wg_waves          = (int) env_unsigned("RT_HIP_FREQ_WG_WAVES", excl ? 12u : (unsigned) rt::FREQ_WG_WAVES, 1, (unsigned) rt::FREQ_WG_WAVES);
     int wg_per_cu         = waves * 4 / wg_waves;
@@ -145,11 +145,11 @@ template <int SF, bool EMIS> int launch_freq(rt_hip_plan *p, hipStream_t stream,
             return fail_arg(msg);
         }
         {
-            const int rc = allow_lds(reinterpret_cast<const void *>(&rt::rt_freq_kernel<SF, EMIS>), p->device, lds, p->lds_limit);
+            const int rc = allow_lds(reinterpret_cast<const void *>(&rt::rt_freq_kernel<SF, EMIS, EXCL>), p->device, lds, p->lds_limit);
             if (rc != RT_OK)
                 return rc;
         }
-        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS>), dim3(grid), dim3((unsigned) wg_waves * 64), lds, stream, a);
+        hipLaunchKernelGGL((rt::rt_freq_kernel<SF, EMIS, EXCL>), dim3(grid), dim3((unsigned) wg_waves * 64), lds, stream, a);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
@@ -162,9 +162,12 @@ int launch_freq_any(rt_hip_plan *p, hipStream_t stream, unsigned tile_begin = 0,
     p->P.tile_end   = tile_end < p->P.n_tiles ? tile_end : p->P.n_tiles;
     p->P.freq_id    = freq_id;
     const int S = p->P.L * RT_N_SUB;
+    if (p->P.use_emis && p->P.exclusive)
+        return (S == 6) ? launch_freq<6, true, true>(p, stream, 0) : launch_freq<0, true, true>(p, stream, 0);
     if (p->P.use_emis)
-        return (S == 6) ? launch_freq<6, true>(p, stream, 0) : launch_freq<0, true>(p, stream, 0);
-    return (S == 6) ? launch_freq<6, false>(p, stream, 0) : launch_freq<0, false>(p, stream, 0);
+        return (S == 6) ? launch_freq<6, true, false>(p, stream, 0) : launch_freq<0, true, false>(p, stream, 0);
+    // (rt_hip_plan_set_ray_grid grants the exclusive mode with emission only)
+    return (S == 6) ? launch_freq<6, false, false>(p, stream, 0) : launch_freq<0, false, false>(p, stream, 0);
 }
 
 } // namespace

@@ -624,7 +624,8 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
                       !getenv("RT_HIP_NO_OWN_CELLS"))
                          ? 1u
                          : 0u;
-    p->P.exclusive = (p->P.own_cells && nga == 1 && ngb == 1 && first == 0 && stride == 1 && count == total) ? 1u : 0u;
+    // (with emission only: the gain-only instance of the frequency kernel carries no exclusive deposit)
+    p->P.exclusive = (p->P.own_cells && p->P.use_emis && nga == 1 && ngb == 1 && first == 0 && stride == 1 && count == total) ? 1u : 0u;
     return RT_OK;
 }
 
