@@ -324,7 +324,7 @@ __device__ __forceinline__ void deposit_index4(const AxisIn (&A)[4], int (&idx)[
 // per-wave LDS scratch of the few-runs deposit: [4][XP_ROW] transposition rows (row stride
 // 66 doubles: 16-byte aligned, rows 4 banks apart) + [FREQ_MAXQ][64] window totals
 constexpr int XP_ROW          = 66;
-constexpr int XS_ROW          = 17; // exclusive mode: staging row of 16 frequencies + 1 (bank spread)
+constexpr int XS_ROW          = 18; // exclusive mode: staging row of 16 frequencies + 2 (bank spread; rows stay 16-byte aligned)
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
 // doubles of dynamic LDS of a work-group (layout: rt_freq_kernel)
@@ -773,7 +773,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         // instruction.
         // The rule (checked per tile, wave-uniform): a full tile whose 64 rays deposit into their own pixels, the pixels
         // nx apart (consecutive rays are consecutive in y: no wrap to the next x inside the tile), K a multiple of the
-        // 16 staged frequencies.  The flush is then 16 x (LDS read at a constant offset, one 64-bit add, store) with no
+        // 16 staged frequencies.  The flush is then 16 x (LDS read at a constant offset, one 64-bit add, a 16-byte store) with no
         // per-row pixel look-up and no range tests -- the general form below costs ~12 instructions per store, a sixth
         // of the deposit's instructions on the 4096^2 x 512 image.
         const int own0        = __builtin_amdgcn_readlane(own_pix, 0);
@@ -787,12 +787,15 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                     mine[j] = v[j];
                 if ((kb & 12) == 12) {
                     __builtin_amdgcn_wave_barrier();
-                    double *dst         = H.image + ((size_t) (own0 + (lane >> 4) * H.nx) * (size_t) K + (size_t) ((kb & ~15) + (lane & 15)));
-                    const size_t gstep  = (size_t) 4 * (size_t) H.nx * (size_t) K; // four image rows on
-                    const double *src   = cache + (lane >> 4) * XS_ROW + (lane & 15);
+                    // 16 bytes per lane: eight lanes cover the 128 staged bytes of a row, a store instruction eight rows
+                    // (half as many store instructions as with 8 bytes per lane: the deposit is bound by store issue)
+                    typedef double f64x2s __attribute__((ext_vector_type(2)));
+                    double *dst         = H.image + ((size_t) (own0 + (lane >> 3) * H.nx) * (size_t) K + (size_t) ((kb & ~15) + 2 * (lane & 7)));
+                    const size_t gstep  = (size_t) 8 * (size_t) H.nx * (size_t) K; // eight image rows on
+                    const double *src   = cache + (lane >> 3) * XS_ROW + 2 * (lane & 7);
 #pragma unroll 4
-                    for (int g = 0; g < WAVE / 4; g++)
-                        dst[(size_t) g * gstep] = src[g * 4 * XS_ROW];
+                    for (int g = 0; g < WAVE / 8; g++)
+                        __builtin_nontemporal_store(*reinterpret_cast<const f64x2s *>(src + g * 8 * XS_ROW), reinterpret_cast<f64x2s *>(dst + (size_t) g * gstep));
                     __builtin_amdgcn_wave_barrier();
                 }
                 return;

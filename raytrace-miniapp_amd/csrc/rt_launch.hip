@@ -104,8 +104,10 @@ template <int SF, bool EMIS, bool EXCL> int launch_freq(rt_hip_plan *p, hipStrea
     // transposition rows (rt_freq.hip: freq_lds_doubles); fewer than 4 rows is not worth having.
     const int waves       = EMIS ? RT_FREQ_WAVES : RT_FREQ_WAVES_SEED;
     constexpr bool excl   = EXCL; // (= p->P.exclusive: launch_freq_any picks the instance)
-    // (exclusive mode is bound by its stores: 12 waves per CU run 3.6 % faster than 16 -- tools/config5_ab.py)
-    int wg_waves          = (int) env_unsigned("RT_HIP_FREQ_WG_WAVES", excl ? 12u : (unsigned) rt::FREQ_WG_WAVES, 1, (unsigned) rt::FREQ_WG_WAVES);
+    // (exclusive mode: while its flush wrote 8 bytes per lane with a pixel look-up per store, 12 waves per CU ran 3.6 %
+    // faster than 16; with the regular-tile flush of 16-byte stores 16 waves win -- 22.15 against 23.0 ms on the
+    // 4096^2 x 512 image, tools/config5_waves.py)
+    int wg_waves          = (int) env_unsigned("RT_HIP_FREQ_WG_WAVES", (unsigned) rt::FREQ_WG_WAVES, 1, (unsigned) rt::FREQ_WG_WAVES);
     int wg_per_cu         = waves * 4 / wg_waves;
     wg_per_cu             = wg_per_cu < 1 ? 1 : wg_per_cu;
     auto lds_of           = [&](int rows) { return rt::freq_lds_doubles(in_lds != 0, (int) p->n_iang, excl, rows, p->P.Kp, wg_waves) * sizeof(double); };
