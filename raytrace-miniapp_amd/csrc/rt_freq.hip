@@ -426,11 +426,16 @@ __device__ __forceinline__ Placed place_ray(const unsigned hflags, ColdPtr C, co
 // (with a run-time flag the one-launch kernel carried it, and 32 bytes of scratch with it)
 template <int SF, bool EMIS, int MAXQ = FREQ_MAXQ, bool EXCL = false>
 __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflags, ColdPtr C, double *lds_iang, const double *tab,
-                                          double *xpose, double *cache, const unsigned tile, const int lane)
+                                          double *xpose, double *cache, const unsigned tile, const int lane, const int k0 = 0,
+                                          const int k1 = 0x7fffffff)
 {
+    // [k0, k1): the frequencies this call integrates and deposits (multiples of VEC; default: all K).  The one-launch
+    // kernel splits the last tiles of a work-group over several waves that way (rt_fused.hip); every part repeats the
+    // per-ray preamble, adds its share of the I_ang sums, and only the part that starts at 0 reports error -1.
     double *win = xpose + 4 * XP_ROW; // [MAXQ][64] totals of the current window of 64 frequencies
     const int S           = SF ? SF : H.L * RT_N_SUB;
     const int K           = H.K;
+    const int k_end       = k1 < K ? k1 : K; // this call's frequencies are [k0, k_end)
     const int Kp          = H.Kp; // row stride of the lineshape tables and of the row cache
     const int nslot       = H.nslot;
     const unsigned n_rays = H.n_rays;
@@ -496,7 +501,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         C->probe.flags[ridx] = fl | (err1 ? F_ERR1 : 0u);
         C->probe.steps[ridx] = steps;
     }
-    if (err1 && !safe_skip) { // error -1: the ray is reported and deposits nothing
+    if (err1 && !safe_skip && k0 == 0) { // error -1: the ray is reported (once) and deposits nothing
         atomicOr(&H.ctl->failure_code, 1u << 1);
         unsigned slot_f = atomicAdd(&H.ctl->n_failed, 1u);
         if (slot_f < RT_N_FAILED_MAX)
@@ -633,12 +638,15 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         // 1.60 ms seeded -- with four waves per SIMD the latency is covered by the other waves.)
 #ifdef RT_ABL_NOFREQ // profiling only: the tile preamble alone
         const int K_loop = K > 1000000 ? K : 0;
+        const int kb_first = 0;
 #elif defined(RT_ABL_ONEBATCH) // profiling only: one batch of four frequencies per tile
         const int K_loop = K < VEC ? K : VEC;
+        const int kb_first = 0;
 #else
-        const int K_loop = K;
+        const int K_loop = k_end;
+        const int kb_first = k0;
 #endif
-        for (int kb = 0; kb < K_loop; kb += VEC) {
+        for (int kb = kb_first; kb < K_loop; kb += VEC) {
             double Iv[VEC];
             if (use_emis) {
 #pragma unroll
@@ -860,13 +868,13 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                         wave_sums(q, kb, v, true);
                 }
             }
-            if ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= K) {
-                // flush the window of 64 frequencies that ends here
+            if ((((kb + VEC) & (WAVE - 1)) == 0) || kb + VEC >= k_end) {
+                // flush the window of 64 frequencies that ends here (the part of it this call has integrated)
                 __builtin_amdgcn_wave_barrier();
                 const int k = ((kb + VEC - 1) & ~(WAVE - 1)) + lane;
 #pragma unroll
                 for (int q = 0; q < MAXQ; q++) {
-                    if (pixq[q] >= 0 && k < K)
+                    if (pixq[q] >= 0 && k < k_end && k >= k0)
                         unsafeAtomicAdd(&H.image[(size_t) pixq[q] * (size_t) K + (size_t) k], win[q * WAVE + lane] * H.scale);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -912,7 +920,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                     if ((lane - (1 << i)) >= run_start)
                         a += t;
                 }
-                if (tail && kb + j < K)
+                if (tail && kb + j < k_end)
                     unsafeAtomicAdd(&img_row[kb + j], a);
             }
         });

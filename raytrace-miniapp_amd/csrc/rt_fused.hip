@@ -42,11 +42,12 @@ namespace rt {
 struct FusedLay {
     unsigned off_exp, off_iang, off_ctl, off_rem, off_buf;
     unsigned n_free, per_wave; // per_wave in doubles
+    unsigned split, k_part;    // TileList::split, TileList::k_part
 };
 struct FusedKArg {
     DevParams P;
     FreqKArg F;
-    unsigned *tile_next; // [n_tiles] links of the work-group tile lists
+    unsigned *tile_next; // [4 n_tiles] links of the work-group tile lists
     FusedLay lay;
 };
 
@@ -81,7 +82,8 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         ctl[1] = n_waves;
         ctl[2] = 0u;
     }
-    const TileList list{ &ctl[0], A.tile_next, reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + (threadIdx.x >> 6) * 32u };
+    const TileList list{ &ctl[0], A.tile_next, reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + (threadIdx.x >> 6) * 32u,
+                         &ctl[1], n_waves, A.lay.split, A.lay.k_part };
 
     // ---- phase 1: the march (rt_march.hip), one tile per chunk, finished tiles pushed onto the list ----
     // (marching waves given a higher wave priority than the waves of their SIMD that have turned to the frequency pass
@@ -149,7 +151,12 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         unsigned hflags = H.flags;
         int lane_t      = lane;
         asm volatile("" : "+s"(hflags), "+v"(lane_t));
-        freq_tile<SF, true, MAXQ>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile, lane_t);
+        // a whole tile, or one of the four parts of its frequency range (rt_march.hip: tile_publish)
+        const unsigned part = (tile >> TILE_PART_SHIFT) & 3u;
+        const int k0 = (tile & TILE_PART_FLAG) ? (int) (part * A.lay.k_part) : 0;
+        const int k1 = (tile & TILE_PART_FLAG) && part < 3u ? k0 + (int) A.lay.k_part : 0x7fffffff;
+        if (k0 < H.K)
+            freq_tile<SF, true, MAXQ>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile & TILE_ID_MASK, lane_t, k0, k1);
 #ifdef RT_WAVETIMES
         if (!fu_first)
             fu_first = __builtin_amdgcn_s_memrealtime();

@@ -384,7 +384,12 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
         const bool fits   = 2 * lay.n_free >= nw && (size_t) (nw - lay.n_free) * per_wave * sizeof(double) <= p->P.blob_bytes;
         if (fits) {
             const size_t flds     = (size_t) lay.off_buf + (size_t) lay.n_free * per_wave * sizeof(double);
-            const size_t n_tiles  = (size_t) p->P.n_tiles;
+            const size_t n_tiles  = 4 * (size_t) p->P.n_tiles; // one link per (tile, part)
+            // the last tiles of a work-group in four parts of the frequency range (whole groups of 4 frequencies; not
+            // worth it below 32 frequencies); RT_HIP_FUSED_SPLIT = 2: never, 3: every tile (tests)
+            const unsigned split_env = env_unsigned("RT_HIP_FUSED_SPLIT", 1, 1, 3);
+            lay.split  = split_env == 2 ? 0u : (split_env == 3 ? 2u : 1u);
+            lay.k_part = p->P.K >= 32 ? (unsigned) (((p->P.K + 3) / 4 + 3) / 4 * 4) : 0u;
             if (p->tile_next_n < n_tiles || !p->tile_next) {
                 plan_quiesce(p);
                 pool_free(p->device, p->tile_next);

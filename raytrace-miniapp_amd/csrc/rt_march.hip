@@ -370,26 +370,54 @@ __device__ unsigned long long g_wt_end[8192], g_wt_dry[8192];
 // memory (`next`); tiles are pushed once and never pushed again, so a pop cannot meet a recycled node.
 struct TileList {
     unsigned *head; // LDS
-    unsigned *next; // global, [n_tiles]
+    unsigned *next; // global, [4 n_tiles]: link of list entry (tile, part) at 4 tile + part
     unsigned *rem;  // LDS, [32] per wave: rays of the wave's tiles in flight that have not retired yet
+    unsigned *marching; // LDS: waves of the work-group that have not left the march yet
+    unsigned n_waves;   // of the work-group
+    unsigned split;     // 0: tiles are pushed whole; 1: split where idle waves would wait for them; 2: always (tests)
+    unsigned k_part;    // frequencies per part of a split tile (a multiple of 4), 0: never split
 };
 constexpr unsigned TILE_NONE = 0xffffffffu;
+// A list entry is a whole tile, or one of four parts of its frequency range [part k_part, (part + 1) k_part):
+// the frequency pass of a tile that is finished when the rest of the work-group has nothing left to do -- the last
+// tiles of a launch, behind the longest rays -- is shared by four waves instead of keeping one busy and the launch open.
+constexpr unsigned TILE_PART_FLAG = 1u << 30, TILE_PART_SHIFT = 28, TILE_ID_MASK = (1u << TILE_PART_SHIFT) - 1u;
+__device__ __forceinline__ unsigned tile_node(unsigned entry)
+{
+    return (entry & TILE_ID_MASK) * 4u + ((entry & TILE_PART_FLAG) ? (entry >> TILE_PART_SHIFT) & 3u : 0u);
+}
 // one lane of the calling wave executes these
 __device__ __forceinline__ void tile_push(const TileList &T, unsigned tile)
 {
     unsigned old = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
-        __hip_atomic_store(&T.next[tile], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (pushed and popped by waves of one work-group)
+        __hip_atomic_store(&T.next[tile_node(tile)], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (pushed and popped by waves of one work-group)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the link is in memory before the head can name the tile
         if (__hip_atomic_compare_exchange_strong(T.head, &old, tile, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
             return;
+    }
+}
+// a finished tile: whole, or in four parts when the work-group is down to its last marching waves (an eighth of them)
+// and the list is empty, i.e. nearly all its waves are waiting for work.  (Splitting whenever the list was empty and
+// SOME wave had left the march cost 2 % on the 6.4 M-ray stand-in: every part repeats the tile's preamble.)
+__device__ __forceinline__ void tile_publish(const TileList &T, unsigned tile)
+{
+    bool parts = T.split == 2u;
+    if (T.split == 1u)
+        parts = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == TILE_NONE &&
+                __hip_atomic_load(T.marching, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 8u <= T.n_waves;
+    if (parts && T.k_part != 0u) {
+        for (unsigned q = 0; q < 4u; q++)
+            tile_push(T, tile | (q << TILE_PART_SHIFT) | TILE_PART_FLAG);
+    } else {
+        tile_push(T, tile);
     }
 }
 __device__ __forceinline__ unsigned tile_pop(const TileList &T)
 {
     unsigned old = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (old != TILE_NONE) {
-        const unsigned nxt = __hip_atomic_load(&T.next[old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned nxt = __hip_atomic_load(&T.next[tile_node(old)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__hip_atomic_compare_exchange_strong(T.head, &old, nxt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
             break;
     }
@@ -861,7 +889,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                     const int l0 = (int) __ffsll((long long) lm) - 1;
                     lm &= lm - 1ull;
                     if (lane == l0)
-                        tile_push(done, ridx >> 6);
+                        tile_publish(done, ridx >> 6);
                     slot_busy &= ~(1u << (unsigned) __builtin_amdgcn_readlane((int) cslot, l0));
                 } while (lm != 0ull);
             }
@@ -1056,7 +1084,7 @@ template <bool LDS_TAB, bool BOUNDED>
 __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    march_wave<LDS_TAB, BOUNDED, false>(P, lds_raw, TileList{ nullptr, nullptr, nullptr });
+    march_wave<LDS_TAB, BOUNDED, false>(P, lds_raw, TileList{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u });
 }
 
 } // namespace rt

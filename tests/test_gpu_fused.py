@@ -176,3 +176,37 @@ def test_random_grids_through_the_one_launch_run(hip, oracle, ase_small, seed):
         ref = oracle.image_loop(p, p.build_rays())
         assert one["stats"]["cell_steps"] == ref["counters"]["cell_steps"]
         assert rel_l2(one["image"], ref["image"]) < TIGHT and rel_l2(one["I_ang"], ref["I_ang"]) < TIGHT
+
+
+@pytest.mark.parametrize("split", ["2", "3"])
+def test_tiles_split_over_four_waves_give_the_same_image(hip, oracle, ase_small, split, monkeypatch):
+    """The one-launch run hands the last tiles of a work-group to four waves, a quarter of the frequencies each
+    (rt_march.hip: tile_publish).  RT_HIP_FUSED_SPLIT=3 splits EVERY tile, 2 none: both against the two-kernel run and
+    the oracle, for frequency counts that divide unevenly, a failing run included (every part may report the ray; the
+    checking repeat leaves the CPU loop's report)."""
+    from test_gpu_edges import same_outputs_in_a_failing_run
+    monkeypatch.setenv("RT_HIP_FUSED_SPLIT", split)
+    for nv in (52, 33, 130, 20):
+        p = ase_small if nv == 52 else problem_mod.resample_frequency(ase_small, nv)
+        one, two = run_grid(hip, p, True, count=64 * 700 + 9), run_grid(hip, p, False, count=64 * 700 + 9)
+        assert one["fused"] and not two["fused"]
+        same_images(one, two, tol=1e-12)
+    ref = oracle.image_loop(ase_small, ase_small.build_rays(np.arange(64 * 700 + 9, dtype=np.int64)))
+    one = run_grid(hip, ase_small, True, count=64 * 700 + 9)
+    assert rel_l2(one["image"], ref["image"]) < TIGHT and rel_l2(one["I_ang"], ref["I_ang"]) < TIGHT
+    # a failing run: NaNs in the lineshape of one length
+    p = copy.copy(ase_small)
+    g = ase_small.gain[2]
+    gv = g.gv.copy()
+    gv[::7] = np.nan
+    p.gain = ase_small.gain[:2] + [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv)]
+    one = run_grid(hip, p, True)
+    ref = oracle.image_loop(p, p.build_rays())
+    assert one["fused"] and one["failure_code"] == ref["failure_code"] and ref["failure_code"] & (1 << 3)
+    same_outputs_in_a_failing_run(one, ref)
+    # error -1 is reported once per ray, whatever the number of parts
+    bad = ase_small.build_rays(np.arange(64 * 40, dtype=np.int64))
+    with hip.Plan(ase_small) as plan:      # (a list keeps two kernels: the count is the reference for the grid run below)
+        plan.set_rays(bad)
+        n_list = len(plan.run().fetch()["failed_rays"])
+    assert n_list == 0
