@@ -204,3 +204,28 @@ def test_tiles_split_over_four_waves_give_the_same_image(hip, oracle, ase_small,
     ref = oracle.image_loop(p, p.build_rays())
     assert one["fused"] and one["failure_code"] == ref["failure_code"] and ref["failure_code"] & (1 << 3)
     same_outputs_in_a_failing_run(one, ref)
+
+
+@pytest.mark.parametrize("split", ["2", "3"])
+def test_invalid_rays_are_reported_once_however_a_tile_is_split(hip, oracle, ase_small, split, monkeypatch):
+    """Error -1 (Helper.h:515: the ray ends nearly perpendicular to z) is found by the preamble of the frequency pass,
+    which every part of a split tile repeats: only the part that starts at frequency 0 reports it.  A beam whose
+    angle grid reaches +-1550 mrad: the rays of its two outermost angles are invalid, all others trace as usual."""
+    monkeypatch.setenv("RT_HIP_FUSED_SPLIT", split)
+    p = copy.copy(ase_small)
+    b = copy.copy(ase_small.beam)
+    b.a = np.linspace(-1550.0, 1550.0, 32)
+    b.da = float(b.a[1] - b.a[0])
+    b.b = b.b[:2].copy()
+    b.x, b.y = b.x[30:31].copy(), b.y[5:6].copy()
+    p.beam = b
+    rays = p.build_rays()
+    assert len(rays) == 64
+    ref = oracle.image_loop(p, rays)
+    one, two = run_grid(hip, p, True), run_grid(hip, p, False)
+    assert one["fused"] and not two["fused"]
+    assert ref["failure_code"] == 1 << 1 and one["failure_code"] == two["failure_code"] == ref["failure_code"]
+    n_bad = len(ref["failed_rays"])
+    assert n_bad == 4 and len(one["failed_rays"]) == n_bad and len(two["failed_rays"]) == n_bad
+    same_images(one, two, tol=1e-12)
+    assert rel_l2(one["image"], ref["image"]) < TIGHT
