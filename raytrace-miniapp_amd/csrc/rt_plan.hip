@@ -39,6 +39,28 @@ struct ArenaBuilder {
     }
 };
 
+// largest magnitude of n floats as bit patterns (non-negative floats order like their bit patterns): `finite` over the
+// values below infinity, `all` over everything.  One pass that the compiler vectorises; the AVX2 instance is
+// taken when the CPU has it (a plan of the shipped size scans 286 000 values on the critical path of every call).
+template <int>
+inline __attribute__((always_inline)) void magnitude_scan(const uint32_t *u, size_t n, uint32_t &finite, uint32_t &all)
+{
+    uint32_t m = 0, mall = 0;
+    for (size_t c = 0; c < n; c++) {
+        uint32_t a = u[c] & 0x7fffffffu;
+        mall       = a > mall ? a : mall;
+        a          = a < 0x7f800000u ? a : 0u; // inf and NaN do not count
+        m          = a > m ? a : m;
+    }
+    finite = m;
+    all    = mall;
+}
+void magnitude_scan_plain(const uint32_t *u, size_t n, uint32_t &finite, uint32_t &all) { magnitude_scan<0>(u, n, finite, all); }
+__attribute__((target("avx2"))) void magnitude_scan_avx2(const uint32_t *u, size_t n, uint32_t &finite, uint32_t &all)
+{
+    magnitude_scan<1>(u, n, finite, all);
+}
+
 } // namespace
 
 // The kernels index rays with 32 bits; the march hands rays out in chunks of at most 4096 (the cap of
@@ -190,6 +212,16 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     lap("device");
     // ---- pack the arena -------------------------------------------------
     ArenaBuilder ab;
+    {
+        // (one allocation instead of a vector that grows under the tables: the estimate only has to be close)
+        size_t estimate = 1 << 16;
+        for (int i = 1; i < N; i++) {
+            const size_t cells = (size_t) gain[i].Nx * (size_t) gain[i].Ny;
+            estimate += cells * ((size_t) ((K + 3) & ~3) * sizeof(float) + sizeof(rt::Node)) +
+                        sizeof(rt::Interval) * ((size_t) gain[i].Nx + (size_t) gain[i].Ny) + 1024;
+        }
+        ab.host.reserve(estimate);
+    }
     std::vector<rt::DevGain> dg((size_t) N);
     std::vector<size_t> off_gv((size_t) N, 0);
     const bool use_emis = gain[0].E0 != nullptr && seed == nullptr; // Helper.h:402
@@ -435,17 +467,12 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         // vectorises)
         float wmax = 0.0f;
         if (use_emis) {
-            uint32_t umax = 0;
+            uint32_t umax          = 0;
+            static const bool avx2 = __builtin_cpu_supports("avx2");
             for (int i = 1; i < N; i++) {
-                const size_t n    = (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K;
-                const uint32_t *u = reinterpret_cast<const uint32_t *>(gain[i].gv);
+                const size_t n = (size_t) gain[i].Nx * (size_t) gain[i].Ny * (size_t) K;
                 uint32_t m = 0, mall = 0;
-                for (size_t c = 0; c < n; c++) {
-                    uint32_t a = u[c] & 0x7fffffffu;
-                    mall       = a > mall ? a : mall;
-                    a          = a < 0x7f800000u ? a : 0u; // inf and NaN do not count
-                    m          = a > m ? a : m;
-                }
+                (avx2 ? magnitude_scan_avx2 : magnitude_scan_plain)(reinterpret_cast<const uint32_t *>(gain[i].gv), n, m, mall);
                 umax = m > umax ? m : umax;
                 if (mall >= 0x7f800000u) // a NaN or an infinity: the frequency kernel then tests every value it reads
                     p->gv_has_nan = true;
@@ -552,30 +579,34 @@ int rt_hip_plan_set_ray_grid(rt_hip_plan *p, const double *gx, int ngx, const do
     (void) hipFree(p->seedtab_dev);
     p->seedtab_dev  = nullptr;
     const size_t nn = (size_t) ngx + (size_t) ngy + (size_t) nga + (size_t) ngb;
-    std::vector<double> h(nn);
+    // one upload: the four grids, then the launch tangents of the a and b values -- Helper.h:409-410,
+    // tanf(1e-3f * ray.a) depends only on the grid value: nga + ngb evaluations on the host, with the same libm
+    // the CPU loop uses
+    const size_t nt = (size_t) nga + (size_t) ngb;
+    std::vector<double> h(nn + (nt + 1) / 2);
     memcpy(h.data(), gx, sizeof(double) * (size_t) ngx);
     memcpy(h.data() + ngx, gy, sizeof(double) * (size_t) ngy);
     memcpy(h.data() + ngx + ngy, ga, sizeof(double) * (size_t) nga);
     memcpy(h.data() + ngx + ngy + nga, gb, sizeof(double) * (size_t) ngb);
-    HIP_TRY(pool_alloc(p->device, (void **) &p->grid_dev, nn * sizeof(double)));
-    HIP_TRY(hipMemcpy(p->grid_dev, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
-    // Helper.h:409-410: tanf(1e-3f * ray.a) depends only on the grid value: nga + ngb
-    // evaluations on the host, with the same libm the CPU loop uses
-    std::vector<float> ht((size_t) nga + (size_t) ngb);
-    for (int k = 0; k < nga; k++)
-        ht[(size_t) k] = tanf(1e-3f * (float) ga[k]);
-    for (int m = 0; m < ngb; m++)
-        ht[(size_t) nga + (size_t) m] = tanf(1e-3f * (float) gb[m]);
-    pool_free(p->device, p->tan_dev);
-    p->tan_dev = nullptr;
-    HIP_TRY(pool_alloc(p->device, (void **) &p->tan_dev, ht.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(p->tan_dev, ht.data(), ht.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        std::vector<float> ht(nt);
+        for (int k = 0; k < nga; k++)
+            ht[(size_t) k] = tanf(1e-3f * (float) ga[k]);
+        for (int m = 0; m < ngb; m++)
+            ht[(size_t) nga + (size_t) m] = tanf(1e-3f * (float) gb[m]);
+        memcpy(h.data() + nn, ht.data(), nt * sizeof(float));
+    }
+    HIP_TRY(pool_alloc(p->device, (void **) &p->grid_dev, h.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(p->grid_dev, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    pool_free(p->device, p->tan_dev); // (the per-ray tangents of a list this plan may have held before)
+    p->tan_dev            = nullptr;
+    const float *tan_grid = reinterpret_cast<const float *>(p->grid_dev + nn);
     p->host_rays   = nullptr;
     rt::DevRays &R = p->P.rays;
     R              = {};
     R.list         = nullptr;
-    R.tan_a        = p->tan_dev;
-    R.tan_b        = p->tan_dev + nga;
+    R.tan_a        = tan_grid;
+    R.tan_b        = tan_grid + nga;
     R.gx           = p->grid_dev;
     R.gy           = p->grid_dev + ngx;
     R.ga           = p->grid_dev + ngx + ngy;
@@ -770,23 +801,26 @@ int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int
         return fail_arg("rt_hip_plan_fetch: plan has not run");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->last_stream));
-    {
-        // rays that failed in the frequency pass have been deposited: repeat the pass without them
-        unsigned code = 0;
-        HIP_TRY(hipMemcpy(&code, &p->ctl->failure_code, sizeof(code), hipMemcpyDeviceToHost));
-        if ((code & ((1u << 2) | (1u << 3))) && !p->path_on && !(p->P.debug & 1u) && !p->repeated) {
-            const int rc = plan_repeat_checked(p);
-            if (rc != RT_OK)
-                return rc;
-            p->repeated = true; // this run's outputs are final; a second fetch must not repeat again
-        }
+    // the control block behind the chunk counters: failure code, failed rays, statistics
+    rt::DevCtl c;
+    constexpr size_t ctl_tail = offsetof(rt::DevCtl, failure_code);
+    auto read_ctl = [&]() {
+        return hipMemcpy(reinterpret_cast<unsigned char *>(&c) + ctl_tail, reinterpret_cast<const unsigned char *>(p->ctl) + ctl_tail,
+                         sizeof(c) - ctl_tail, hipMemcpyDeviceToHost);
+    };
+    HIP_TRY(read_ctl());
+    // rays that failed in the frequency pass have been deposited: repeat the pass without them
+    if ((c.failure_code & ((1u << 2) | (1u << 3))) && !p->path_on && !(p->P.debug & 1u) && !p->repeated) {
+        const int rc = plan_repeat_checked(p);
+        if (rc != RT_OK)
+            return rc;
+        p->repeated = true; // this run's outputs are final; a second fetch must not repeat again
+        HIP_TRY(read_ctl());
     }
     if (image)
         HIP_TRY(hipMemcpy(image, p->last_image, p->n_image * sizeof(double), hipMemcpyDeviceToHost));
     if (I_ang)
         HIP_TRY(hipMemcpy(I_ang, p->last_iang, p->n_iang * sizeof(double), hipMemcpyDeviceToHost));
-    rt::DevCtl c;
-    HIP_TRY(hipMemcpy(&c, p->ctl, sizeof(c), hipMemcpyDeviceToHost));
     if (failure_code)
         *failure_code = c.failure_code;
     int nf = (int) (c.n_failed < RT_N_FAILED_MAX ? c.n_failed : RT_N_FAILED_MAX);

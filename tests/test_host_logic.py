@@ -144,6 +144,34 @@ def test_ray_list_that_is_not_a_grid_is_rejected():
     assert backend.ray_list_grid_dims(neg) is None
 
 
+def test_ray_list_check_sees_one_flipped_bit_anywhere():
+    """The bit-wise check behind the recognition, in both of its forms (one thread up to 16 MB of list, host threads
+    beyond) and on a list that is only 4-byte aligned, as a vector of four-float rays may be."""
+    import numpy as np
+    backend = importlib.import_module("raytrace-miniapp_amd.backend")
+    cabi = importlib.import_module("raytrace-miniapp_amd.cabi")
+    for dims in ((9, 7, 11, 13), (40, 30, 37, 29)):                       # 144 KB and 20.6 MB of list
+        rays = _grid_rays(*dims, seed=3)
+        n = len(rays)
+        raw = np.zeros(n * 16 + 4, np.uint8)
+        off = raw[4:].view(cabi.RAY_DTYPE)                                 # the same list, 4 bytes off 8-byte alignment
+        off[:] = rays
+        assert off.ctypes.data % 8 == 4 or off.ctypes.data % 8 == 0
+        for lst in (rays, off):
+            assert backend.ray_list_grid_dims(lst) == dims
+            rng = np.random.default_rng(n)
+            spots = [0, 1, n - 1, n - 2, n // 2] + list(rng.integers(2, n - 2, 6))
+            # ray 0 and the first ray of each period define the guess itself: a flip there changes the guessed grid,
+            # and the rest of the list then disagrees with it
+            for r in spots:
+                for f in ("x", "y", "a", "b"):
+                    keep = lst[f][r]
+                    lst[f][r] = np.nextafter(keep, np.float32(9))
+                    assert backend.ray_list_grid_dims(lst) != dims, (dims, int(r), f)
+                    lst[f][r] = keep
+            assert backend.ray_list_grid_dims(lst) == dims
+
+
 # ---- bench.py / multigpu plumbing that needs no GPU ---------------------------------------------------
 def test_bench_module_does_not_touch_torch_before_it_spawns_its_ranks():
     """`python bench.py --gpus N` starts its ranks as a torch.distributed.run child; that is only safe if
