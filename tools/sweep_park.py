@@ -3,7 +3,11 @@ import importlib, os, sys
 sys.path.insert(0, '.')
 rt = importlib.import_module("raytrace-miniapp_amd")
 be = importlib.import_module("raytrace-miniapp_amd.backend")
-p = rt.scale_problem(rt.datfile.load('tests/golden/ASE_small.dat.xz'), 16.0)
+# CASE=seed: the seeded input (seed_small.dat) instead of the ASE stand-in
+if os.environ.get("CASE") == "seed":
+    p = rt.datfile.load('tests/golden/seed_small.dat.xz')
+else:
+    p = rt.scale_problem(rt.datfile.load('tests/golden/ASE_small.dat.xz'), 16.0)
 for park in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 24, 32]:
     os.environ["RT_HIP_MARCH_PARK"] = str(park)
     with be.Plan(p) as plan:
