@@ -993,7 +993,7 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
         lap("set_ray_grid");
         if (rc == RT_OK)
             rc = rt_hip_plan_run(p, q, nullptr, nullptr); // asynchronous
-        lap("run (launch)");
+        lap(p->last_fused ? "run (one launch)" : "run (two launches)");
         if (rc == RT_OK && !verify_ray_grid(rays, n_rays, G, host_threads(16))) {
             as_grid = false; // not that grid after all: the speculative result is discarded below
             plan_quiesce(p);
