@@ -515,10 +515,13 @@ def measure_cabi_multi(n_dev: int, workload: str, share_gpu: bool) -> dict:
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                         "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a collective that never completes ends the child's call after a minute (rt_multi.hip), and the child itself is
+    # given five: the bench line must not wait a quarter of an hour for a sub-record
+    env.setdefault("RT_HIP_MULTI_TIMEOUT_MS", "60000")
     if share_gpu and n_dev > 1:  # rehearsal on a box with fewer GPUs than ranks
         env["RT_HIP_MULTI_LOOPBACK"] = str(n_dev)
     r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cabi-multi-child", str(n_dev), "--workload", workload],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=300)
     for ln in r.stdout.splitlines():
         if ln.startswith("CABI_MULTI "):
             return json.loads(ln[len("CABI_MULTI "):])
