@@ -172,6 +172,23 @@ def test_ray_list_check_sees_one_flipped_bit_anywhere():
             assert backend.ray_list_grid_dims(lst) == dims
 
 
+def test_every_environment_switch_is_in_the_table_of_integration_md():
+    """INTEGRATION.md holds ONE table of the RT_* environment variables the library, the adapter and the Python host
+    read; a switch added to the code without a row there fails here."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    pkg = root / "raytrace-miniapp_amd"
+    names = set()
+    for f in list((pkg / "csrc").glob("*.hip")) + list((pkg / "csrc").glob("*.h")) + list((pkg / "host").glob("*.cpp")) + \
+            list(pkg.glob("*.py")):
+        names |= set(re.findall(r'"(RT_[A-Z][A-Z_0-9]+)"', f.read_text()))
+    assert len(names) >= 20, names
+    doc = (root / "INTEGRATION.md").read_text()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
+
+
 # ---- bench.py / multigpu plumbing that needs no GPU ---------------------------------------------------
 def test_bench_module_does_not_touch_torch_before_it_spawns_its_ranks():
     """`python bench.py --gpus N` starts its ranks as a torch.distributed.run child; that is only safe if
