@@ -224,7 +224,7 @@ def cpu_baseline(problem, cell_steps: int) -> dict:
         while the first few finish (measured in round 3: 8.9x over one core on 16 threads);
       * `physical_cores`: the same with one thread per physical core;
       * `one_core`: every 16th pixel's rays on one thread, scaled by the sample's own ray-step count.
-    2 runs each, min and mean; the threads are started before the clock and released together."""
+    3 runs each, min and mean; the threads are started before the clock and released together."""
     import numpy as np
     from oracle.binding import Oracle, Reference
 
@@ -241,7 +241,7 @@ def cpu_baseline(problem, cell_steps: int) -> dict:
         run = lambda r: eng.image_loop(problem, r, n_threads=1)  # noqa: E731
     by_pixel = rays[: n_pix * per_pixel].reshape(n_pix, per_pixel)
 
-    def timed(cpus: list, runs: int = 2) -> dict:
+    def timed(cpus: list, runs: int = 3) -> dict:
         T = max(1, min(len(cpus), n_pix))
         parts = [np.ascontiguousarray(by_pixel[t::T].reshape(-1)) for t in range(T)]
         if n > n_pix * per_pixel:  # (a ragged tail, never the case for a grid)
@@ -279,7 +279,7 @@ def cpu_baseline(problem, cell_steps: int) -> dict:
         sample = problem.build_rays(ids)
         steps_sample = int(Oracle().image_loop(problem, sample, n_threads=min(16, info["available"]))["counters"]["cell_steps"])
         t1 = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             run(sample)
             t1.append(time.perf_counter() - t0)
@@ -358,6 +358,75 @@ def measure_config5(torch, backend, rt, problem_mod, dev, counters: dict) -> dic
     rec["traffic"] = c5.get("hbm_bytes_per_step")
     rec["traffic_source"] = (counters.get("_source") + " (config5 counter pass)") if c5 else None
     return rec
+
+
+def cpu_config5_sample(rt, problem_mod, full_rays: int, full_steps: int) -> dict:
+    """CPU figure for BASELINE config 5: the reference cannot run it (nv = 512 is beyond its K_MAX), so
+    the bit-identical C restatement (kind "port") is timed on a SAMPLE -- every 8th pixel in x and in y of the 4096 x 4096
+    grid, 262 144 rays spread over the whole image, the cell sizes and tables of the full problem -- on the host threads of
+    the box, and on one thread for every 64th pixel; the whole image is that time scaled by the ray count."""
+    import copy
+
+    import numpy as np
+    from oracle.binding import Oracle
+
+    info = cpu_info()
+    eng = Oracle()
+    p = config5_problem(rt, problem_mod, 4096)
+
+    def sample(stride, part=0, parts=1):
+        q = copy.copy(p)
+        b = copy.copy(p.beam)
+        b.x = np.ascontiguousarray(p.beam.x[stride // 2::stride][part::parts])
+        b.y = np.ascontiguousarray(p.beam.y[stride // 2::stride])
+        q.beam = b
+        return q
+
+    def timed(stride, cpus, runs=3):
+        # one sub-problem per thread (its own pixel columns, its own small image: a private copy of the sample's
+        # 268 MB image per thread, as the thread loop of the restatement keeps them, would be the thing measured)
+        T = max(1, min(len(cpus), len(p.beam.x[stride // 2::stride])))
+        subs = [sample(stride, t, T) for t in range(T)]
+        t, steps = [], 0
+        me = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+        try:
+            for _ in range(runs):
+                gate = threading.Barrier(T + 1)
+                got = [0] * T
+
+                def work(i):
+                    try:
+                        os.sched_setaffinity(0, {cpus[i]})
+                    except (AttributeError, OSError):
+                        pass
+                    gate.wait()
+                    got[i] = int(eng.image_loop(subs[i], n_threads=1)["counters"]["cell_steps"])
+
+                th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+                for x in th:
+                    x.start()
+                gate.wait()
+                t0 = time.perf_counter()
+                for x in th:
+                    x.join()
+                t.append(time.perf_counter() - t0)
+                steps = sum(got)
+        finally:
+            if me is not None:
+                os.sched_setaffinity(0, me)
+        n = sum(q.n_rays_total for q in subs)
+        return {"rays": n, "ray_steps": steps, "threads": T, "seconds_min": min(t), "seconds_mean": sum(t) / len(t),
+                "runs": runs, "value": steps / min(t), "unit": "ray-steps/s",
+                "ms_per_image_extrapolated": min(t) * 1e3 * full_rays / n}
+
+    many = timed(8, info["cpus"])
+    one = timed(64, info["cpus"][:1])
+    return {"value": many["value"], "unit": "ray-steps/s", "cores": many["threads"], "kind": "port",
+            "ms_per_image_extrapolated": many["ms_per_image_extrapolated"], "all_threads": many, "one_core": one,
+            "full_problem": {"rays": full_rays, "ray_steps": full_steps},
+            "sample": "every 8th pixel in x and y (262 144 rays over the whole image, full-size cells and tables, nv = 512), "
+                      "pixel columns dealt round-robin to pinned host threads, one small image each; one core: every 64th pixel; "
+                      "the reference itself stops at nv < K_MAX = 100"}
 
 
 def measure_seed_medium(torch, backend, rt, dev, counters: dict) -> dict:
@@ -830,6 +899,12 @@ def main() -> int:
                 plan.close()
                 try:
                     line["roofline_config5"] = measure_config5(torch, backend, rt, problem_mod, dev, counters)
+                    if not args.no_cpu_baseline:
+                        c5 = line["roofline_config5"]
+                        try:
+                            c5["cpu_baseline"] = cpu_config5_sample(rt, problem_mod, c5["rays"], c5["ray_steps"])
+                        except Exception as exc:  # noqa: BLE001
+                            c5["cpu_baseline"] = {"error": repr(exc)}
                 except Exception as exc:  # noqa: BLE001
                     line["roofline_config5"] = {"error": repr(exc)}
             if args.workload == "standin" and not args.no_seed_medium:

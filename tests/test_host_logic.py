@@ -274,6 +274,28 @@ def test_cpu_baseline_uses_every_hardware_thread_of_the_affinity_mask(ase_small)
     assert "round-robin" in rec["sample"] and "pinned" in rec["sample"]
 
 
+def test_cpu_figure_for_config_5_is_a_sample_with_small_private_images():
+    """bench.py `cpu_config5_sample` (the reference cannot run nv = 512, the restatement is timed on a
+    sample and scaled by the ray count): every thread traces its own pixel columns into its own small image, the
+    samples cover the whole grid, and the main thread's affinity is restored."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    problem_mod = importlib.import_module("raytrace-miniapp_amd.problem")
+    before = sorted(os.sched_getaffinity(0))
+    rec = bench.cpu_config5_sample(rt, problem_mod, 4096 * 4096, 146242923)
+    assert sorted(os.sched_getaffinity(0)) == before
+    a, o = rec["all_threads"], rec["one_core"]
+    assert rec["kind"] == "port" and a["rays"] == 512 * 512 and o["rays"] == 64 * 64 and o["threads"] == 1
+    assert a["threads"] == min(len(before), 512) == rec["cores"]
+    # both samples see the same mix of rays: ray-steps per ray agree to a few per cent, and with the full problem's
+    assert abs(a["ray_steps"] / a["rays"] - o["ray_steps"] / o["rays"]) < 0.05 * a["ray_steps"] / a["rays"]
+    assert abs(a["ray_steps"] / a["rays"] - 146242923 / 4096 ** 2) < 0.05 * a["ray_steps"] / a["rays"]
+    assert a["value"] >= 0.8 * o["value"] and rec["ms_per_image_extrapolated"] == a["ms_per_image_extrapolated"] > 0
+
+
 def test_bench_accounting_of_the_contract_formula():
     """B_read = 16 R + C_step S + 4 K 3 L R [+ (256 + 8 K) R_live]; the ASE_small figures of the
     survey (962 MB) must come out of bench.algorithmic_bytes."""
