@@ -4,6 +4,7 @@
 // genuine list (Helper.h:409-410) and the probe that decides who computes them.  Host code only.
 #include "rt_runtime.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -55,29 +56,34 @@ bool guess_ray_grid(const rt_ray *rays, size_t n, GridGuess &G)
 // every ray of the list against the grid.  A ray is two 64-bit words, (x, y) and (a, b): the rays of one pixel
 // share the first word, and their second words are the same na * nb patterns for every pixel -- one table, built
 // once -- so a pixel is one straight loop of two integer compares per ray that the compiler vectorises (the AVX2
-// instance is taken when the CPU has it).  One thread checks a list of up to 16 MB faster than threads can be started
-// (6.4 MB of ASE_small: ~0.25 ms, beside a 0.4 ms launch); longer lists go to up to `threads` host threads: ~1 ms for
-// the 102 MB of a 6.4 M-ray list on 16 threads, hidden behind the kernels it runs beside.
+// instance is taken when the CPU has it).  Grids with few rays per pixel (na * nb < 64; one ray per pixel in
+// BASELINE config 5) are compared a piece of a pixel column at a time instead, against tables that span the column
+// (the y half of the first word varies along it).  One thread checks a list of up to 16 MB faster than threads can be
+// started (6.4 MB of ASE_small: 0.1 - 0.2 ms, beside a 0.4 ms launch); longer lists go to up to `threads` host
+// threads: ~1 ms for the 102 MB of a 6.4 M-ray list on 16 threads, hidden behind the kernels it runs beside.
 namespace {
-template <int>
-inline __attribute__((always_inline)) uint64_t pixel_diff(const unsigned char *rays, const uint64_t *ab, size_t nab, uint64_t xy)
+// rays[0 .. n) against first word = xw | y_part[q] (y_part == nullptr: xw alone) and second word = ab[q]
+template <bool WITH_Y>
+inline __attribute__((always_inline)) uint64_t run_diff(const unsigned char *rays, const uint64_t *y_part, const uint64_t *ab, size_t n,
+                                                        uint64_t xw)
 {
     uint64_t d0 = 0, d1 = 0;
-    for (size_t q = 0; q < nab; q++) {
+    for (size_t q = 0; q < n; q++) {
         uint64_t w[2]; // (a list of four-float rays is 4-byte aligned only)
         memcpy(w, rays + 16 * q, 16);
-        d0 |= w[0] ^ xy;
+        d0 |= w[0] ^ (WITH_Y ? xw | y_part[q] : xw);
         d1 |= w[1] ^ ab[q];
     }
     return d0 | d1;
 }
-uint64_t pixel_diff_plain(const unsigned char *rays, const uint64_t *ab, size_t nab, uint64_t xy)
+uint64_t run_diff_plain(const unsigned char *rays, const uint64_t *y_part, const uint64_t *ab, size_t n, uint64_t xw)
 {
-    return pixel_diff<0>(rays, ab, nab, xy);
+    return y_part ? run_diff<true>(rays, y_part, ab, n, xw) : run_diff<false>(rays, y_part, ab, n, xw);
 }
-__attribute__((target("avx2"))) uint64_t pixel_diff_avx2(const unsigned char *rays, const uint64_t *ab, size_t nab, uint64_t xy)
+__attribute__((target("avx2"))) uint64_t run_diff_avx2(const unsigned char *rays, const uint64_t *y_part, const uint64_t *ab, size_t n,
+                                                       uint64_t xw)
 {
-    return pixel_diff<1>(rays, ab, nab, xy);
+    return y_part ? run_diff<true>(rays, y_part, ab, n, xw) : run_diff<false>(rays, y_part, ab, n, xw);
 }
 } // namespace
 
@@ -98,19 +104,46 @@ bool verify_ray_grid(const rt_ray *rays, size_t n, const GridGuess &G, unsigned 
     for (size_t k = 0; k < na; k++)
         for (size_t m = 0; m < nb; m++)
             ab[k * nb + m] = bits(G.g[2][k]) | bits(G.g[3][m]) << 32;
+    // few rays per pixel: tables over a whole pixel column (unless that would be a table of more than 2^20 entries)
+    const bool by_column = nab < 64 && ny * nab <= ((size_t) 1 << 20);
+    std::vector<uint64_t> col_y, col_ab;
+    if (by_column) {
+        col_y.resize(ny * nab);
+        col_ab.resize(ny * nab);
+        for (size_t j = 0; j < ny; j++)
+            for (size_t q = 0; q < nab; q++) {
+                col_y[j * nab + q]  = by[j];
+                col_ab[j * nab + q] = ab[q];
+            }
+    }
     const size_t pixels = n / nab;
     threads             = threads < 1 ? 1 : threads;
     if (n * sizeof(rt_ray) <= (size_t) 16 << 20)
         threads = 1;
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    const auto diff        = avx2 ? pixel_diff_avx2 : pixel_diff_plain;
+    const auto diff        = avx2 ? run_diff_avx2 : run_diff_plain;
     std::atomic<bool> ok(true);
-    auto work = [&](size_t p0, size_t p1) {
-        uint64_t d = 0;
-        for (size_t px = p0; px < p1; px++) {
-            d |= diff(reinterpret_cast<const unsigned char *>(rays + px * nab), ab.data(), nab, bx[px / ny] | by[px % ny]);
-            if ((px & 63) == 63 && (d != 0 || !ok.load(std::memory_order_relaxed)))
-                break;
+    auto work = [&](size_t p0, size_t p1) { // pixels p0 .. p1 of the list (pixel = i * ny + j)
+        uint64_t d     = 0;
+        size_t checked = 0;
+        for (size_t px = p0; px < p1 && d == 0;) {
+            const unsigned char *at = reinterpret_cast<const unsigned char *>(rays + px * nab);
+            const size_t i = px / ny, j = px % ny;
+            size_t step = 1;
+            if (by_column) {
+                // up to the end of this pixel column, of this thread's range, and of a piece of ~4096 rays
+                step = std::min(std::min(ny - j, p1 - px), std::max<size_t>(1, 4096 / nab));
+                d |= diff(at, col_y.data() + j * nab, col_ab.data() + j * nab, step * nab, bx[i]);
+            } else {
+                d |= diff(at, nullptr, ab.data(), nab, bx[i] | by[j]);
+            }
+            px += step;
+            checked += step * nab;
+            if (checked >= 65536) { // has another thread found a difference?
+                checked = 0;
+                if (!ok.load(std::memory_order_relaxed))
+                    break;
+            }
         }
         if (d != 0)
             ok.store(false, std::memory_order_relaxed);

@@ -150,7 +150,9 @@ def test_ray_list_check_sees_one_flipped_bit_anywhere():
     import numpy as np
     backend = importlib.import_module("raytrace-miniapp_amd.backend")
     cabi = importlib.import_module("raytrace-miniapp_amd.cabi")
-    for dims in ((9, 7, 11, 13), (40, 30, 37, 29)):                       # 144 KB and 20.6 MB of list
+    # 144 KB and 20.6 MB of list with many rays per pixel; few rays per pixel (compared a piece of a pixel column at a
+    # time): small, 30.7 MB, one ray per pixel, and a column too long for a column table
+    for dims in ((9, 7, 11, 13), (40, 30, 37, 29), (5, 40, 3, 2), (64, 5000, 3, 2), (300, 200, 1, 1), (2, 600000, 2, 1)):
         rays = _grid_rays(*dims, seed=3)
         n = len(rays)
         raw = np.zeros(n * 16 + 4, np.uint8)
@@ -158,7 +160,9 @@ def test_ray_list_check_sees_one_flipped_bit_anywhere():
         off[:] = rays
         assert off.ctypes.data % 8 == 4 or off.ctypes.data % 8 == 0
         for lst in (rays, off):
-            assert backend.ray_list_grid_dims(lst) == dims
+            got = backend.ray_list_grid_dims(lst)
+            assert got is not None and [d for d in got if d > 1] == [d for d in dims if d > 1]
+            dims = got                                                     # (axes of length 1 may be named differently)
             rng = np.random.default_rng(n)
             spots = [0, 1, n - 1, n - 2, n // 2] + list(rng.integers(2, n - 2, 6))
             # ray 0 and the first ray of each period define the guess itself: a flip there changes the guessed grid,
