@@ -611,8 +611,9 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true", help="only the timed loop (profiling runs)")
     ap.add_argument("--no-small", action="store_true", help="skip the ASE_small / seed_small sub-record of the default N = 1 run")
     ap.add_argument("--no-cabi-multi", action="store_true", help="skip the rt_hip_multi_image_loop sub-record (a child process)")
-    ap.add_argument("--clock-ramp-steps", type=int, default=64,
-                    help="further untimed steps after --warmup, before the timed region (reported in `warmup`)")
+    ap.add_argument("--clock-ramp-steps", type=int, default=None,
+                    help="further untimed steps after --warmup, before the timed region (reported in `warmup`): 64, or 0 "
+                         "with --no-extras, unless given")
     ap.add_argument("--cabi-multi-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-assemble", action="store_true",
                     help="N > 1: leave the tiles on their GPUs (config 5: gathering the 68.7 GB image takes longer than "
@@ -682,7 +683,7 @@ def main() -> int:
     # starts (the first timed steps run 5-15 % longer than the steady state).  --clock-ramp-steps further UNTIMED
     # steps (default 64, the same on every rank) let the K timed steps see the clock a production loop sees; the
     # line's `warmup` is the total number of untimed steps that ran, `warmup_requested` the --warmup part of it.
-    extra_warm = 0 if args.no_extras else max(0, args.clock_ramp_steps)
+    extra_warm = max(0, args.clock_ramp_steps) if args.clock_ramp_steps is not None else (0 if args.no_extras else 64)
     for _ in range(extra_warm):
         step()
     torch.cuda.synchronize()

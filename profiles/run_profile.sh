@@ -20,7 +20,9 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps $STEPS --warmup 3 --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/bench_trace.log" 2>&1
+# (the trace pass runs the untimed clock-ramp steps of the default bench command as well, so that its last $STEPS
+# launches are the timed ones of the bench line: summarize.py averages those beside the all-calls average)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD --clock-ramp-steps 64 > "$OUT/bench_trace.log" 2>&1
 echo "trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $CMD > "$OUT/bench_fetch.log" 2>&1
 echo "fetch done"
@@ -48,4 +50,4 @@ echo "sm trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/sm_fetch" -o pmc -- $SM > "$OUT/sm_fetch.log" 2>&1 || echo "sm fetch failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/sm_write" -o pmc -- $SM > "$OUT/sm_write.log" 2>&1 || echo "sm write failed"
 echo "sm pmc done"
-python3 profiles/summarize.py "$OUT" "$TAG" "$HEAD" > "$OUT/summary.json"; tail -3 "$OUT/bench_trace.log"
+python3 profiles/summarize.py "$OUT" "$TAG" "$HEAD" "$STEPS" > "$OUT/summary.json"; tail -3 "$OUT/bench_trace.log"

@@ -29,6 +29,24 @@ def which(name):
     return None
 
 
+def timed_calls(root, sub, steps):
+    """Average duration of the LAST `steps` launches of each kernel of the path in a kernel-trace pass: the launches
+    bench.py times (its warm-up and clock-ramp launches come first)."""
+    f = find(Path(root) / sub, "*kernel_trace.csv")
+    if f is None or not steps:
+        return {}
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = which(r.get("Kernel_Name", ""))
+        if k:
+            per[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out = {}
+    for k, v in per.items():
+        last = [d for _, d in sorted(v)[-steps:]]
+        out[k] = {"calls": len(last), "avg_ns": sum(last) / len(last), "min_ns": min(last), "max_ns": max(last)}
+    return out
+
+
 def kernel_stats(root, out_csv, sub="trace"):
     f = find(Path(root) / sub, "*kernel_stats.csv")
     if f is None:
@@ -107,6 +125,8 @@ def main():
     here = Path(__file__).resolve().parent
     out = {"tag": tag, "git_head": sys.argv[3] if len(sys.argv) > 3 else None, "kernel_source_hash": kernel_source_hash(),
            "kernels": list(KERNELS), "kernel_trace": kernel_stats(root, here / f"{tag}_kernel_stats.csv")}
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    out["kernel_trace_timed_steps"] = timed_calls(root, "trace", steps)
     fetch, write, sq = pmc(root, "pmc_fetch"), pmc(root, "pmc_write"), pmc(root, "pmc_sq")
     out["pmc_fetch"], out["pmc_write"], out["pmc_sq"] = fetch, write, sq
     hbm = {}
