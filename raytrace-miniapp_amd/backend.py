@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import subprocess
+import time
 from pathlib import Path
 
 import numpy as np
@@ -267,13 +268,15 @@ def image_loop(problem: Problem, rays: np.ndarray | None = None, device: int = 0
     nf = C.c_int(0)
     failed = np.zeros(cabi.RT_N_FAILED_MAX, dtype=cabi.RAY_DTYPE)
     st = cabi.RtStats()
+    t0 = time.perf_counter()
     rc = hl.lib.rt_hip_image_loop(device, m.N, C.byref(m.beam), m.gain, m.seed_ref, problem.method,
                                   cabi.rays_ptr(rays), len(rays), problem.scale, cabi._dp(image),
                                   cabi._dp(iang), C.byref(code), cabi.rays_ptr(failed),
                                   cabi.RT_N_FAILED_MAX, C.byref(nf), C.byref(st))
+    call_ms = (time.perf_counter() - t0) * 1e3  # the C call alone (what a C++ caller of the adapter waits for)
     hl.check(rc, "rt_hip_image_loop")
     return dict(image=image, I_ang=iang, failure_code=code.value, failed_rays=failed[:nf.value].copy(),
-                stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_})
+                stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_}, call_ms=call_ms)
 
 
 def multi_image_loop(problem: Problem, rays: np.ndarray | None = None, n_devices: int = 0) -> dict:
@@ -292,13 +295,16 @@ def multi_image_loop(problem: Problem, rays: np.ndarray | None = None, n_devices
     nf = C.c_int(0)
     failed = np.zeros(cabi.RT_N_FAILED_MAX, dtype=cabi.RAY_DTYPE)
     st = cabi.RtStats()
+    t0 = time.perf_counter()
     rc = hl.lib.rt_hip_multi_image_loop(n_devices, m.N, C.byref(m.beam), m.gain, m.seed_ref, problem.method,
                                         cabi.rays_ptr(rays), len(rays), problem.scale, cabi._dp(image),
                                         cabi._dp(iang), C.byref(code), cabi.rays_ptr(failed),
                                         cabi.RT_N_FAILED_MAX, C.byref(nf), C.byref(st))
+    call_ms = (time.perf_counter() - t0) * 1e3
     hl.check(rc, "rt_hip_multi_image_loop")
     return dict(image=image, I_ang=iang, failure_code=code.value, failed_rays=failed[:nf.value].copy(),
-                stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_}, mode=int(hl.lib.rt_hip_multi_last_mode()))
+                stats={k: getattr(st, k) for k, _ in cabi.RtStats._fields_}, mode=int(hl.lib.rt_hip_multi_last_mode()),
+                call_ms=call_ms)
 
 
 def ray_list_grid_dims(rays: np.ndarray):
