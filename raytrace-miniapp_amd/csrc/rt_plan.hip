@@ -14,27 +14,67 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 
 using namespace rtr;
 
 namespace {
 
-// Bump allocator over a host staging image of the device arena.
+// Bump allocator over the host image of a plan's arena: one buffer of a capacity computed up front (an upper bound, so nothing moves while the
+// tables are copied in), page-locked when the upload is to run beside host work (rt_hip_image_loop), plain otherwise.
 struct ArenaBuilder {
-    std::vector<unsigned char> host;
-    size_t put(const void *src, size_t bytes)
+    unsigned char *base = nullptr;
+    size_t cap = 0, used = 0;
+    bool pinned = false, overflow = false;
+    std::unique_ptr<unsigned char[]> own;
+    ArenaBuilder() = default;
+    ArenaBuilder(const ArenaBuilder &) = delete;
+    ArenaBuilder &operator=(const ArenaBuilder &) = delete;
+    ~ArenaBuilder()
     {
-        size_t off = align_up(host.size(), 256);
-        host.resize(off + bytes);
-        if (bytes && src)
-            memcpy(host.data() + off, src, bytes);
+        if (pinned)
+            rtr::pinned_free(base);
+    }
+    void start(size_t capacity, bool want_pinned)
+    {
+        cap = capacity;
+        void *h = nullptr;
+        if (want_pinned && rtr::pinned_alloc(&h, capacity) == hipSuccess) {
+            base   = static_cast<unsigned char *>(h);
+            pinned = true;
+        } else {
+            own.reset(new unsigned char[capacity]);
+            base = own.get();
+        }
+    }
+    // hands the page-locked buffer to the caller (who frees it with pinned_free once the upload has completed)
+    void *release()
+    {
+        pinned = false;
+        return base;
+    }
+    size_t reserve(size_t bytes) // zero-filled
+    {
+        const size_t off = rtr::align_up(used, 256);
+        if (off + bytes > cap) {
+            overflow = true;
+            return 0;
+        }
+        memset(base + off, 0, bytes);
+        used = off + bytes;
         return off;
     }
-    size_t reserve(size_t bytes)
+    size_t put(const void *src, size_t bytes)
     {
-        size_t off = align_up(host.size(), 256);
-        host.resize(off + bytes);
+        const size_t off = rtr::align_up(used, 256);
+        if (off + bytes > cap) {
+            overflow = true;
+            return 0;
+        }
+        if (bytes && src)
+            memcpy(base + off, src, bytes);
+        used = off + bytes;
         return off;
     }
 };
@@ -114,6 +154,12 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         return;
     (void) hipSetDevice(p->device);
     plan_quiesce(p); // kernels of an unfetched (or failed) run may still use the buffers parked below
+    if (p->staging) {
+        if (hipStreamSynchronize(p->upload_q) != hipSuccess)
+            (void) hipGetLastError();
+        pinned_free(p->staging);
+        p->staging = nullptr;
+    }
     if (p->ring.empty()) {
         if (p->ev0)
             (void) hipEventDestroy(p->ev0);
@@ -144,6 +190,14 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
 
 int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam, const rt_gain *gain,
                        const rt_seed *seed, int method, double scale)
+{
+    return rtr::plan_create_on(out, nullptr, device, N, beam, gain, seed, method, scale);
+}
+
+} // extern "C"
+
+int rtr::plan_create_on(rt_hip_plan **out, hipStream_t upload_q, int device, int N, const rt_beam *beam, const rt_gain *gain,
+                        const rt_seed *seed, int method, double scale)
 {
     if (!out || !beam || !gain)
         return fail_arg("rt_hip_plan_create: NULL argument");
@@ -213,14 +267,22 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     // ---- pack the arena -------------------------------------------------
     ArenaBuilder ab;
     {
-        // (one allocation instead of a vector that grows under the tables: the estimate only has to be close)
-        size_t estimate = 1 << 16;
+        // capacity: every piece below, each rounded up to the 256-byte alignment of its offset
+        auto piece      = [](size_t bytes) { return align_up(bytes, 256) + 256; };
+        const size_t kp = (size_t) ((K + 3) & ~3);
+        size_t capacity = piece(sizeof(rt::DevGain) * (size_t) N), blob_bytes = align_up(sizeof(rt::BlobGain) * (size_t) N, 16);
         for (int i = 1; i < N; i++) {
             const size_t cells = (size_t) gain[i].Nx * (size_t) gain[i].Ny;
-            estimate += cells * ((size_t) ((K + 3) & ~3) * sizeof(float) + sizeof(rt::Node)) +
-                        sizeof(rt::Interval) * ((size_t) gain[i].Nx + (size_t) gain[i].Ny) + 1024;
+            capacity += piece(cells * kp * sizeof(float));
+            blob_bytes += sizeof(rt::Interval) * ((size_t) gain[i].Nx + (size_t) gain[i].Ny) + sizeof(rt::Node) * cells;
         }
-        ab.host.reserve(estimate);
+        capacity += piece(blob_bytes);
+        capacity += piece(sizeof(double) * (size_t) beam->nx) + piece(sizeof(double) * (size_t) beam->ny) +
+                    piece(sizeof(double) * (size_t) beam->na) + piece(sizeof(double) * (size_t) beam->nb) + 2 * piece(sizeof(double) * kp);
+        if (seed)
+            for (int i = 0; i < 5; i++)
+                capacity += 2 * piece(sizeof(double) * ((size_t) (seed->dim[i] > 0 ? seed->dim[i] : 0) + kp));
+        ab.start(capacity, upload_q != nullptr);
     }
     std::vector<rt::DevGain> dg((size_t) N);
     std::vector<size_t> off_gv((size_t) N, 0);
@@ -235,8 +297,8 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         if (Kp == K) {
             off_gv[(size_t) i] = ab.put(gain[i].gv, sizeof(float) * cells * (size_t) K);
         } else {
-            off_gv[(size_t) i] = ab.reserve(sizeof(float) * cells * (size_t) Kp); // resize() zero-fills
-            float *dst         = reinterpret_cast<float *>(ab.host.data() + off_gv[(size_t) i]);
+            off_gv[(size_t) i] = ab.reserve(sizeof(float) * cells * (size_t) Kp); // zero-filled
+            float *dst         = reinterpret_cast<float *>(ab.base + off_gv[(size_t) i]);
             for (size_t c = 0; c < cells; c++)
                 memcpy(dst + c * (size_t) Kp, gain[i].gv + c * (size_t) K, sizeof(float) * (size_t) K);
         }
@@ -246,11 +308,11 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     const size_t off_ba  = ab.put(beam->a, sizeof(double) * (size_t) beam->na);
     const size_t off_bb  = ab.put(beam->b, sizeof(double) * (size_t) beam->nb);
     const size_t off_bdv = ab.reserve(sizeof(double) * (size_t) Kp);
-    memcpy(ab.host.data() + off_bdv, beam->dv, sizeof(double) * (size_t) beam->nv);
+    memcpy(ab.base + off_bdv, beam->dv, sizeof(double) * (size_t) beam->nv);
     const size_t off_bdv2 = ab.reserve(sizeof(double) * (size_t) Kp); // 2 * dv (exact), RayTraceImageCPU.cpp:66
     for (int k = 0; k < beam->nv; k++) {
         const double d2 = 2.0 * beam->dv[k];
-        memcpy(ab.host.data() + off_bdv2 + sizeof(double) * (size_t) k, &d2, sizeof(double));
+        memcpy(ab.base + off_bdv2 + sizeof(double) * (size_t) k, &d2, sizeof(double));
     }
     size_t off_sx[5] = { 0 }, off_sf[5] = { 0 };
     if (seed) {
@@ -266,7 +328,7 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
             off_sx[i] = ab.put(seed->x[i], sizeof(double) * (size_t) seed->dim[i]);
             if (i == 4) { // the frequency profile, padded like the lineshape rows
                 off_sf[i] = ab.reserve(sizeof(double) * (size_t) Kp);
-                memcpy(ab.host.data() + off_sf[i], seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
+                memcpy(ab.base + off_sf[i], seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
             } else {
                 off_sf[i] = ab.put(seed->f[i], sizeof(double) * (size_t) seed->dim[i]);
             }
@@ -382,7 +444,11 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         }                                                \
     } while (0)
 
-    p->arena_bytes = align_up(ab.host.size(), 256);
+    if (ab.overflow) {
+        delete p;
+        return fail_arg("rt_hip_plan_create: internal error, the arena outgrew its computed capacity");
+    }
+    p->arena_bytes = align_up(ab.used, 256);
     PLAN_TRY(pool_alloc(device, (void **) &p->arena, p->arena_bytes));
     unsigned char *A = p->arena;
     p->gv_dev.assign((size_t) N, nullptr);
@@ -391,8 +457,17 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
         p->gv_dev[(size_t) i] = dg[(size_t) i].gv;
     }
     p->dv2_dev = reinterpret_cast<const double *>(A + off_bdv2);
-    memcpy(ab.host.data() + off_gain, dg.data(), sizeof(rt::DevGain) * (size_t) N);
-    PLAN_TRY(hipMemcpy(p->arena, ab.host.data(), ab.host.size(), hipMemcpyHostToDevice));
+    memcpy(ab.base + off_gain, dg.data(), sizeof(rt::DevGain) * (size_t) N);
+    if (upload_q && ab.pinned) {
+        // queued, not waited for: the staging buffer stays with the plan until the queue has been waited for
+        // (rt_hip_plan_destroy), and every reader of the tables runs on this queue (rt_hip_image_loop)
+        const size_t bytes = ab.used;
+        p->staging         = ab.release();
+        p->upload_q        = upload_q;
+        PLAN_TRY(hipMemcpyAsync(p->arena, p->staging, bytes, hipMemcpyHostToDevice, upload_q));
+    } else {
+        PLAN_TRY(hipMemcpy(p->arena, ab.base, ab.used, hipMemcpyHostToDevice));
+    }
     lap("alloc + upload");
 
     rt::DevParams &P = p->P;
@@ -488,8 +563,6 @@ int rt_hip_plan_create(rt_hip_plan **out, int device, int N, const rt_beam *beam
     lap("rest");
     return RT_OK;
 }
-
-} // extern "C"
 
 // rt_hip_image_loop only: the list stays on the host until the run, which uploads it in slices
 // beside the march (the caller's buffer outlives the call, the plan does not)
@@ -977,12 +1050,19 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
             t_prev = now;
         }
     };
+    // The call's own queue first: the tables travel on it from page-locked staging while the host goes on (grid
+    // recognition, the small uploads, the launch), and everything that reads them is launched on it.
+    hipStream_t q  = lease_queue(device);
     rt_hip_plan *p = nullptr;
-    int rc         = rt_hip_plan_create(&p, device, N, beam, gain, seed, method, scale);
-    if (rc != RT_OK)
+    int rc         = plan_create_on(&p, q, device, N, beam, gain, seed, method, scale);
+    if (rc != RT_OK) {
+        release_queue(device, q);
         return rc;
+    }
+    // (the seed-factor tables of a seeded plan are filled by a kernel outside this queue: rt_hip_plan_set_ray_grid)
+    if (seed && q && hipStreamSynchronize(q) != hipSuccess)
+        (void) hipGetLastError();
     lap("plan_create");
-    hipStream_t q = lease_queue(device);
     // A list that is a whole tensor grid (what create_image builds) is not uploaded: the device
     // generates the rays while host threads check the list against the grid, ray by ray.
     GridGuess G;

@@ -63,6 +63,14 @@ struct PoolBlock {
 std::mutex g_pool_mutex;
 std::vector<PoolBlock> g_pool;
 std::unordered_map<void *, size_t> g_pool_sizes; // live blocks handed out by pool_alloc
+// page-locked host staging blocks (pinned_alloc below), under the same mutex
+struct PinnedBlock {
+    void *ptr;
+    size_t bytes;
+};
+std::vector<PinnedBlock> g_pinned;                 // parked
+std::unordered_map<void *, size_t> g_pinned_sizes; // handed out
+constexpr size_t PINNED_MAX_BLOCKS = 8;
 } // namespace
 
 hipError_t pool_alloc(int device, void **out, size_t bytes)
@@ -111,10 +119,14 @@ hipError_t pool_alloc(int device, void **out, size_t bytes)
 void pool_trim_all()
 {
     std::vector<PoolBlock> drop;
+    std::vector<PinnedBlock> drop_pinned;
     {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
         drop.swap(g_pool);
+        drop_pinned.swap(g_pinned);
     }
+    for (auto &b : drop_pinned)
+        (void) hipHostFree(b.ptr);
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     for (auto &b : drop) {
@@ -136,6 +148,57 @@ hipError_t dev_malloc(void **out, size_t bytes)
         e = hipMalloc(out, bytes ? bytes : 16);
     }
     return e;
+}
+
+// Page-locked host staging (the arena of a plan created by rt_hip_image_loop travels from it while the host goes on):
+// hipHostMalloc costs ~0.1 ms and more, so freed blocks are parked like device blocks -- at most eight, best fit.
+hipError_t pinned_alloc(void **out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes == 0)
+        bytes = 16;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        int best = -1;
+        for (size_t i = 0; i < g_pinned.size(); i++)
+            if (g_pinned[i].bytes >= bytes && g_pinned[i].bytes <= 2 * bytes && (best < 0 || g_pinned[i].bytes < g_pinned[(size_t) best].bytes))
+                best = (int) i;
+        if (best >= 0) {
+            *out                 = g_pinned[(size_t) best].ptr;
+            g_pinned_sizes[*out] = g_pinned[(size_t) best].bytes;
+            g_pinned.erase(g_pinned.begin() + best);
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        g_pinned_sizes[*out] = bytes;
+    } else {
+        (void) hipGetLastError();
+        *out = nullptr;
+    }
+    return e;
+}
+
+void pinned_free(void *ptr)
+{
+    if (!ptr)
+        return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        size_t bytes = 0;
+        auto it      = g_pinned_sizes.find(ptr);
+        if (it != g_pinned_sizes.end()) {
+            bytes = it->second;
+            g_pinned_sizes.erase(it);
+        }
+        if (bytes && g_pinned.size() < PINNED_MAX_BLOCKS && bytes <= ((size_t) 256 << 20)) {
+            g_pinned.push_back({ ptr, bytes });
+            return;
+        }
+    }
+    (void) hipHostFree(ptr);
 }
 
 // tuning overrides from the environment: a missing, non-numeric or non-positive value keeps the default
@@ -203,8 +266,10 @@ hipStream_t lease_queue(int device)
         }
     }
     hipStream_t q = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) {
+        (void) hipGetLastError(); // the caller goes on without a queue of its own (and reports a bad device itself)
         return nullptr;
+    }
     return q;
 }
 void release_queue(int device, hipStream_t q)

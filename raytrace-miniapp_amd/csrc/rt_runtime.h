@@ -24,6 +24,8 @@ struct rt_hip_plan {
     rt::DevParams P    = {};
     unsigned char *arena = nullptr;
     size_t arena_bytes = 0;
+    void *staging        = nullptr; // page-locked source of an arena upload still in flight on upload_q (plan_create_on)
+    hipStream_t upload_q = nullptr;
     rt_ray *rays_dev   = nullptr;
     double *grid_dev   = nullptr; // ray grids when rays are generated
     float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
@@ -97,6 +99,9 @@ void pool_free(int device, void *ptr);
 void pool_trim_all();
 // hipMalloc for the large one-off allocations: out of memory while the pool still parks blocks -> trim and retry
 hipError_t dev_malloc(void **out, size_t bytes);
+// page-locked host staging for uploads that run beside host work (parked like device blocks; rt_pool.hip)
+hipError_t pinned_alloc(void **out, size_t bytes);
+void pinned_free(void *ptr);
 
 // tuning overrides from the environment: a missing, non-numeric or non-positive value keeps the default
 unsigned env_unsigned(const char *name, unsigned def, unsigned lo, unsigned hi);
@@ -112,6 +117,10 @@ void release_queue(int device, hipStream_t q);
 void plan_quiesce(rt_hip_plan *p);
 // the list stays on the host until the run, which uploads it in slices beside the march
 int plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_rays);
+// rt_hip_plan_create with the table upload queued on `upload_q` from page-locked staging instead of waited for (nullptr:
+// what rt_hip_plan_create does).  Everything that reads the tables must then run on that queue, or after a wait for it.
+int plan_create_on(rt_hip_plan **out, hipStream_t upload_q, int device, int N, const rt_beam *beam, const rt_gain *gain,
+                   const rt_seed *seed, int method, double scale);
 // most rays a list may hold (the kernels index rays with 32 bits)
 extern const size_t MAX_LIST_RAYS;
 
