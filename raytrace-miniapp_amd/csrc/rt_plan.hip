@@ -160,6 +160,8 @@ void rt_hip_plan_destroy(rt_hip_plan *p)
         pinned_free(p->staging);
         p->staging = nullptr;
     }
+    pinned_free(p->out_staging);
+    p->out_staging = nullptr;
     if (p->ring.empty()) {
         if (p->ev0)
             (void) hipEventDestroy(p->ev0);
@@ -564,6 +566,37 @@ int rtr::plan_create_on(rt_hip_plan **out, hipStream_t upload_q, int device, int
     return RT_OK;
 }
 
+// rt_hip_image_loop only: the outputs of a run that are a few megabytes at most follow its kernels down the queue into
+// page-locked staging -- one wait in rt_hip_plan_fetch instead of a wait and three blocking copies (larger images are
+// fetched directly: copying them once more on the host would cost what the queueing saves).
+void rtr::plan_stage_outputs(rt_hip_plan *p)
+{
+    constexpr size_t ctl_tail = offsetof(rt::DevCtl, failure_code), ctl_bytes = sizeof(rt::DevCtl) - ctl_tail;
+    if (!p || !p->ran || !p->last_stream)
+        return;
+    const size_t off_ang = align_up(ctl_bytes, 256), off_img = off_ang + align_up(p->n_iang * sizeof(double), 256);
+    const size_t total   = off_img + p->n_image * sizeof(double);
+    if (total > ((size_t) 4 << 20))
+        return;
+    if (!p->out_staging) {
+        void *h = nullptr;
+        if (pinned_alloc(&h, total) != hipSuccess)
+            return;
+        p->out_staging = static_cast<unsigned char *>(h);
+    }
+    hipError_t e = hipMemcpyAsync(p->out_staging, reinterpret_cast<const unsigned char *>(p->ctl) + ctl_tail, ctl_bytes,
+                                  hipMemcpyDeviceToHost, p->last_stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(p->out_staging + off_ang, p->last_iang, p->n_iang * sizeof(double), hipMemcpyDeviceToHost, p->last_stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(p->out_staging + off_img, p->last_image, p->n_image * sizeof(double), hipMemcpyDeviceToHost, p->last_stream);
+    if (e != hipSuccess) {
+        (void) hipGetLastError(); // fetched the ordinary way
+        return;
+    }
+    p->out_staged = true;
+}
+
 // rt_hip_image_loop only: the list stays on the host until the run, which uploads it in slices
 // beside the march (the caller's buffer outlives the call, the plan does not)
 int rtr::plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_rays)
@@ -864,6 +897,7 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     p->last_iang   = iang_dev;
     p->ran         = true;
     p->repeated    = false;
+    p->out_staged  = false;
     return RT_OK;
 }
 
@@ -876,24 +910,38 @@ int rt_hip_plan_fetch(rt_hip_plan *p, double *image, double *I_ang, unsigned int
     HIP_TRY(hipStreamSynchronize(p->last_stream));
     // the control block behind the chunk counters: failure code, failed rays, statistics
     rt::DevCtl c;
-    constexpr size_t ctl_tail = offsetof(rt::DevCtl, failure_code);
+    constexpr size_t ctl_tail = offsetof(rt::DevCtl, failure_code), ctl_bytes = sizeof(rt::DevCtl) - ctl_tail;
     auto read_ctl = [&]() {
         return hipMemcpy(reinterpret_cast<unsigned char *>(&c) + ctl_tail, reinterpret_cast<const unsigned char *>(p->ctl) + ctl_tail,
-                         sizeof(c) - ctl_tail, hipMemcpyDeviceToHost);
+                         ctl_bytes, hipMemcpyDeviceToHost);
     };
-    HIP_TRY(read_ctl());
+    // (outputs that travelled behind the kernels already: plan_stage_outputs)
+    bool staged = p->out_staged && p->out_staging;
+    if (staged)
+        memcpy(reinterpret_cast<unsigned char *>(&c) + ctl_tail, p->out_staging, ctl_bytes);
+    else
+        HIP_TRY(read_ctl());
     // rays that failed in the frequency pass have been deposited: repeat the pass without them
     if ((c.failure_code & ((1u << 2) | (1u << 3))) && !p->path_on && !(p->P.debug & 1u) && !p->repeated) {
         const int rc = plan_repeat_checked(p);
         if (rc != RT_OK)
             return rc;
-        p->repeated = true; // this run's outputs are final; a second fetch must not repeat again
+        p->repeated   = true; // this run's outputs are final; a second fetch must not repeat again
+        p->out_staged = staged = false;
         HIP_TRY(read_ctl());
     }
-    if (image)
-        HIP_TRY(hipMemcpy(image, p->last_image, p->n_image * sizeof(double), hipMemcpyDeviceToHost));
-    if (I_ang)
-        HIP_TRY(hipMemcpy(I_ang, p->last_iang, p->n_iang * sizeof(double), hipMemcpyDeviceToHost));
+    if (staged) {
+        const size_t off_ang = align_up(ctl_bytes, 256), off_img = off_ang + align_up(p->n_iang * sizeof(double), 256);
+        if (image)
+            memcpy(image, p->out_staging + off_img, p->n_image * sizeof(double));
+        if (I_ang)
+            memcpy(I_ang, p->out_staging + off_ang, p->n_iang * sizeof(double));
+    } else {
+        if (image)
+            HIP_TRY(hipMemcpy(image, p->last_image, p->n_image * sizeof(double), hipMemcpyDeviceToHost));
+        if (I_ang)
+            HIP_TRY(hipMemcpy(I_ang, p->last_iang, p->n_iang * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (failure_code)
         *failure_code = c.failure_code;
     int nf = (int) (c.n_failed < RT_N_FAILED_MAX ? c.n_failed : RT_N_FAILED_MAX);
@@ -1073,6 +1121,8 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
         lap("set_ray_grid");
         if (rc == RT_OK)
             rc = rt_hip_plan_run(p, q, nullptr, nullptr); // asynchronous
+        if (rc == RT_OK)
+            plan_stage_outputs(p);
         lap(p->last_fused ? "run (one launch)" : "run (two launches)");
         if (rc == RT_OK && !verify_ray_grid(rays, n_rays, G, host_threads(16))) {
             as_grid = false; // not that grid after all: the speculative result is discarded below
@@ -1084,6 +1134,8 @@ int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gai
         rc = plan_set_rays_deferred(p, rays, n_rays);
         if (rc == RT_OK)
             rc = rt_hip_plan_run(p, q, nullptr, nullptr);
+        if (rc == RT_OK)
+            plan_stage_outputs(p);
     }
     if (rc == RT_OK)
         rc = rt_hip_plan_fetch(p, image, I_ang, failure_code, failed_rays, max_failed, n_failed, stats);

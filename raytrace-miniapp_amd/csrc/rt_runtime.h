@@ -26,6 +26,8 @@ struct rt_hip_plan {
     size_t arena_bytes = 0;
     void *staging        = nullptr; // page-locked source of an arena upload still in flight on upload_q (plan_create_on)
     hipStream_t upload_q = nullptr;
+    unsigned char *out_staging = nullptr; // page-locked copy of the last run's outputs, queued behind its kernels (plan_stage_outputs)
+    bool out_staged            = false;
     rt_ray *rays_dev   = nullptr;
     double *grid_dev   = nullptr; // ray grids when rays are generated
     float *tan_dev     = nullptr; // tangents: grid mode [nga + ngb], list mode [2 n_rays]
@@ -117,6 +119,9 @@ void release_queue(int device, hipStream_t q);
 void plan_quiesce(rt_hip_plan *p);
 // the list stays on the host until the run, which uploads it in slices beside the march
 int plan_set_rays_deferred(rt_hip_plan *p, const rt_ray *rays, size_t n_rays);
+// after rt_hip_plan_run: queues the download of control block, I_ang and image (if they are small) behind the kernels, into
+// page-locked staging, so that rt_hip_plan_fetch finds them on the host when the queue has drained
+void plan_stage_outputs(rt_hip_plan *p);
 // rt_hip_plan_create with the table upload queued on `upload_q` from page-locked staging instead of waited for (nullptr:
 // what rt_hip_plan_create does).  Everything that reads the tables must then run on that queue, or after a wait for it.
 int plan_create_on(rt_hip_plan **out, hipStream_t upload_q, int device, int N, const rt_beam *beam, const rt_gain *gain,
