@@ -183,6 +183,26 @@ def test_failure_codes_match_the_cpu_loop(hip, oracle, ase_small):
         hip.create_image(p, "hip")
 
 
+def test_failing_runs_through_the_host_pointer_entry(hip, oracle, ase_small):
+    """rt_hip_image_loop queues the download of its (small) outputs behind the kernels; a run with failing rays repeats
+    its frequency pass afterwards, so what was queued is stale and must not be what the caller gets -- for a list traced
+    as a list and for the whole grid handed over as a list (recognised, generated on the device)."""
+    p = copy.copy(ase_small)
+    g = ase_small.gain[2]
+    for gv in (-np.abs(g.gv), np.where(np.arange(g.gv.size) % 7 == 0, np.nan, g.gv).astype(np.float32)):
+        p.gain = ase_small.gain[:2] + [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, gv, g.Nv)]
+        ids = np.arange(0, ase_small.n_rays_total, 997, dtype=np.int64)
+        for rays in (ase_small.build_rays(ids), ase_small.build_rays()):
+            ref = oracle.image_loop(p, rays, n_threads=8)
+            out = hip.image_loop(p, rays)
+            assert ref["failure_code"] & ((1 << 2) | (1 << 3)) and out["failure_code"] == ref["failure_code"]
+            same_outputs_in_a_failing_run(out, ref)
+    # and a clean call right after, on the staging the failing ones used
+    ok = hip.image_loop(ase_small)
+    want = run_hip(hip, ase_small)
+    assert ok["failure_code"] == 0 and rel_l2(ok["image"], want["image"]) < 1e-12 and rel_l2(ok["I_ang"], want["I_ang"]) < 1e-12
+
+
 def _ray_set(rays):
     return sorted(tuple(np.asarray(r.tolist(), dtype=np.float32).view(np.uint32).tolist()) for r in rays)
 
