@@ -177,7 +177,9 @@ int rt_hip_host_libm_mode(int device);
 
 /* Device allocations -- never data -- are kept across calls (ray lists, tangents, march records;
  * Readme.txt:43 forbids caching data only).  This returns every parked block of every device to the
- * driver; RT_HIP_POOL_MAX_MB in the environment caps what may be parked (default 32768). */
+ * driver; RT_HIP_POOL_MAX_MB in the environment caps what may be parked (default 32768).  The host-pointer entry
+ * points also park up to eight page-locked staging buffers (tables on their way up, small outputs on their way
+ * down, at most 256 MB each); this call frees those too. */
 void rt_hip_pool_trim(void);
 
 /*
