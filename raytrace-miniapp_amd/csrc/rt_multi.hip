@@ -307,6 +307,10 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                 fail(RT_ERR_HIP, "no queue");
         }
         std::vector<double> xd;
+        // the tables travel on the worker's queue from page-locked staging while the worker goes on to its grid and its
+        // buffers (the run is launched on the same queue); a seeded plan fills its seed-factor tables with a kernel
+        // outside the queue and therefore waits for its upload as rt_hip_plan_create does
+        const hipStream_t up_q = seed ? nullptr : q;
         if (w.rc == RT_OK) {
             int rc;
             if (tiles) {
@@ -320,7 +324,7 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                     bd.nx = 1;
                     bd.x  = xd.data();
                 }
-                rc = rt_hip_plan_create(&p, pd, N, &bd, gain, seed, method, scale);
+                rc = plan_create_on(&p, up_q, pd, N, &bd, gain, seed, method, scale);
                 if (rc == RT_OK) {
                     const int cols      = tile_cols(nx, d, ndev);
                     const int64_t count = (int64_t) cols * ny * beam->na * beam->nb;
@@ -328,7 +332,7 @@ int rt_hip_multi_image_loop(int ndev, int N, const rt_beam *beam, const rt_gain 
                                                   beam->nb, 0, 1, count);
                 }
             } else {
-                rc = rt_hip_plan_create(&p, pd, N, beam, gain, seed, method, scale);
+                rc = plan_create_on(&p, up_q, pd, N, beam, gain, seed, method, scale);
                 // contiguous ray chunks, as RayTraceImageThreadLoop splits them (RayTraceImage.cpp:107)
                 const size_t chunk = n_rays / (size_t) ndev + 1;
                 const size_t begin = std::min((size_t) d * chunk, n_rays);
