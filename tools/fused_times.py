@@ -8,7 +8,8 @@ be = importlib.import_module("raytrace-miniapp_amd.backend")
 mg = importlib.import_module("raytrace-miniapp_amd.multigpu")
 lib = be.HipLibrary(be.CSRC / "librt_hip_wt.so")
 full = rt.scale_problem(rt.datfile.load('tests/golden/ASE_small.dat.xz'), 16.0)
-for name, p in (("N=1", full), ("N=8 shard", mg.shard(full, 0, 8))):
+small = rt.datfile.load('tests/golden/ASE_small.dat.xz')
+for name, p in (("N=1", full), ("N=8 shard", mg.shard(full, 0, 8)), ("ASE_small.dat", small)):
     with be.Plan(p, lib=lib) as plan:
         plan.set_ray_grid()
         s = (C.c_ulonglong * 8)(); e = (C.c_ulonglong * 8192)(); d = (C.c_ulonglong * 8192)()
