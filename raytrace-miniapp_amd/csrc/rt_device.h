@@ -178,6 +178,11 @@ struct DevParams {
     // 1: never mark a ray F_SKIP (rt_march.hip): a lineshape table holds a NaN or an infinity, and on the CPU even a
     // ray with all-zero sums reads row ivl = 0 of every table and fails with 0 * NaN (Helper.h:543-594)
     unsigned int no_skip;
+    // watchdog of the march instance for tables / step sizes outside the verified ranges (rt_march.hip): iterations of a
+    // wave since it last took rays after which the rays it holds are given up as invalid (error -1).  The reference
+    // would loop for ever on a ray whose steps do not advance (an infinite dz, say) -- on a GPU that is a hung device,
+    // not a hung process.  2^24 by default, four orders of magnitude above the longest ray of the shipped inputs.
+    unsigned int spin_limit;
     unsigned char *rec;
     unsigned int rec_stride;
     unsigned int chunk; // rays a wave reserves per fetch of the global ray counter

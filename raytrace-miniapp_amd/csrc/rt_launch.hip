@@ -332,6 +332,7 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     // stand-in: 2.36 ms at 1, flat optimum 2.12 ms at 8 ... 24, 2.63 ms at 40)
     p->P.park    = env_unsigned("RT_HIP_MARCH_PARK", 12, 1, 64);
     p->P.path_on = p->path_on ? 1u : 0u;
+    p->P.spin_limit = env_unsigned("RT_HIP_MARCH_SPIN_LIMIT", 1u << 24, 1024, 0x7fffffffu); // (tests lower it)
     p->P.no_skip = p->gv_has_nan ? 1u : 0u; // the CPU loop multiplies 0 * gv[row 0] for sub-segments a ray never entered
     if (p->path_on) {
         const size_t n2 = (size_t) p->P.L * RT_N_SUB + 1;

@@ -538,6 +538,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
 #ifdef RT_INSTRUMENT
     unsigned ray_iters = 0;
 #endif
+    unsigned spin = 0; // (BOUNDED = false only)
     for (;;) {
         RT_MARK(5); // [C] of the previous iteration
 #ifdef RT_INSTRUMENT
@@ -551,7 +552,28 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         const int n_idle              = (int) __popcll(idle);
         if (n_idle == WAVE && !more)
             break;
+        // Watchdog of the instance that takes tables and step sizes as they come (BOUNDED = false: something is outside
+        // the ranges rt_hip_plan_create verifies -- an index far from 1, a gradient beyond 1e12, a dz beyond 1e6 cm).
+        // The reference's loops have no iteration limit, and with such inputs a ray's steps can stop advancing (an
+        // infinite dz in a medium without refraction: 1250 cm per step towards z = inf); on the CPU that is a busy
+        // process, here it would be a hung device.  `spin` counts the wave's iterations since it last took rays (while the
+        // counters have rays that is every few dozen iterations; afterwards a wave lives as long as its longest ray); a
+        // wave that reaches P.spin_limit -- looked at every 4096 iterations -- gives its rays up: escaped, direction
+        // zeroed, so that they commit what they have, retire through [A1] and are reported as invalid rays (error -1)
+        // by the frequency pass, as rays with a NaN start are.  The BOUNDED instance carries no such counter (it costs
+        // 1 - 2 % of the march): inside the verified ranges every step advances by a bounded fraction of a bounded box.
+        if (!BOUNDED) {
+            if (((++spin) & 0xfffu) == 0u && spin >= P.spin_limit) {
+                spin = 0;
+                if (st != ST_IDLE) {
+                    escaped = true;
+                    sx = sy = sz = 0.0f;
+                    st           = ST_CELL;
+                }
+            }
+        }
         if (more && (n_idle >= REFILL)) {
+            spin = 0;
             const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (idle >> 32),
                                                              __builtin_amdgcn_mbcnt_lo((unsigned) idle, 0u));
             int need = n_idle, off = 0;

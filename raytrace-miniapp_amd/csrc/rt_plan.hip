@@ -423,7 +423,9 @@ int rtr::plan_create_on(rt_hip_plan **out, hipStream_t upload_q, int device, int
                 all_bounded = false;
         }
     }
-    if (!(beam->dz >= 1e-12 && beam->dz <= 1e12))
+    // (dz: a straight ray in a medium without refraction advances by up to 1250 cm per integrator step, Helper.h:288-297;
+    // 1e6 cm keeps a sub-segment within a few hundred steps -- beyond it the instance with the watchdog marches)
+    if (!(beam->dz >= 1e-12 && beam->dz <= 1e6))
         all_bounded = false;
     p->tables_bounded = all_bounded;
     if (tiny_spacing) {

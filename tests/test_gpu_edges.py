@@ -203,6 +203,58 @@ def test_failing_runs_through_the_host_pointer_entry(hip, oracle, ase_small):
     assert ok["failure_code"] == 0 and rel_l2(ok["image"], want["image"]) < 1e-12 and rel_l2(ok["I_ang"], want["I_ang"]) < 1e-12
 
 
+_SPIN_CHILD = """
+import copy, importlib, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+rt = importlib.import_module("raytrace-miniapp_amd")
+hip = importlib.import_module("raytrace-miniapp_amd.backend")
+base = rt.datfile.load({dat!r})
+p = copy.copy(base)
+# no refraction at all (n = 1 everywhere) and an infinite segment length: a ray along z never reaches the end of its
+# sub-segment and never leaves the plasma -- Helper.h:279-311 steps 1250 cm at a time towards z = inf
+p.gain = [base.gain[0]] + [rt.Gain(g.x, g.y, np.ones_like(g.n), g.g0, g.E0, g.gv, g.Nv) for g in base.gain[1:]]
+p.beam = copy.copy(base.beam)
+p.beam.dz = float("inf")
+rays = np.zeros(3, dtype=rt.cabi.RAY_DTYPE)
+rays["x"] = 0.5 * (base.gain[1].x[0] + base.gain[1].x[-1])
+rays["y"] = [0.3 * base.gain[1].y[-1], 0.5 * base.gain[1].y[-1], 0.7 * base.gain[1].y[-1]]
+with hip.Plan(p) as plan:
+    out = plan.set_rays(rays).run().fetch()
+print("LIST", out["failure_code"], len(out["failed_rays"]), float(np.abs(out["image"]).max()), flush=True)
+# the same through the one-launch run: a whole grid whose launch angles include (0, 0)
+pm = importlib.import_module("raytrace-miniapp_amd.problem")
+q = pm.regrid_beam(p, nx=12, ny=6)
+q.beam.a = q.beam.da * (np.arange(7) - 3.0)            # 7 x 5 launch angles around (0, 0): one ray per pixel spins
+q.beam.b = q.beam.db * (np.arange(5) - 2.0)
+with hip.Plan(q) as plan:
+    out = plan.set_ray_grid().run().fetch()
+    print("GRID", out["failure_code"], out["stats"]["n_rays"], plan.last_fused(), flush=True)
+# and the library is fine afterwards
+ok = hip.image_loop(base)
+print("AFTER", ok["failure_code"], ok["stats"]["cell_steps"], flush=True)
+"""
+
+
+def test_a_ray_that_never_advances_is_given_up_not_marched_for_ever():
+    """The reference's loops have no iteration limit: a ray whose steps do not advance (here: an infinite dz in a medium
+    without refraction) keeps the CPU busy for ever.  On the device that would be a hung GPU; the march gives a wave's
+    rays up as invalid (error -1) after RT_HIP_MARCH_SPIN_LIMIT iterations without a single ray retiring or arriving
+    (default 2^24; lowered here).  Run in a child process under a time limit: a hang is the failure this guards against."""
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    env = dict(os.environ)
+    env["RT_HIP_MARCH_SPIN_LIMIT"] = "4096"
+    code = _SPIN_CHILD.format(root=str(ROOT), dat=str(GOLDEN / "ASE_small.dat.xz"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LIST 2 3 0.0" in r.stdout, r.stdout
+    grid = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("GRID")][0]
+    assert int(grid[1]) & 2 and int(grid[2]) > 0, r.stdout
+    assert "AFTER 0 4768067" in r.stdout, r.stdout
+
+
 def _ray_set(rays):
     return sorted(tuple(np.asarray(r.tolist(), dtype=np.float32).view(np.uint32).tolist()) for r in rays)
 
