@@ -127,6 +127,10 @@ int rt_hip_selftest(int device, unsigned long long *n_checked, unsigned long lon
  * If failure_code comes back non-zero, image and I_ang hold exactly what RayTraceImageCPULoop leaves:
  * the failing rays deposit nothing (RayTraceImageCPU.cpp:29-36) -- the frequency pass is repeated in a
  * checking mode for such a run.
+ * Two kinds of ray on which the reference's loops never end are reported as invalid rays (error -1) instead of
+ * being marched: a ray that starts inside the plasma with a NaN position or direction, and -- for tables or a dz
+ * outside the ranges rt_hip_plan_create verifies -- the rays of a wave that has marched 2^24 iterations without
+ * taking a new ray (steps that do not advance: an infinite dz in a medium without refraction).
  */
 int rt_hip_image_loop(int device, int N, const rt_beam *beam, const rt_gain *gain,
                       const rt_seed *seed, int method, const rt_ray *rays, size_t n_rays,
