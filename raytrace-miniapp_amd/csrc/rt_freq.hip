@@ -327,10 +327,18 @@ constexpr int XP_ROW          = 66;
 constexpr int XS_ROW          = 18; // exclusive mode: staging row of 16 frequencies + 2 (bank spread; rows stay 16-byte aligned)
 constexpr int FREQ_MAXQ       = 3;
 constexpr int FREQ_WAVE_XPOSE = 4 * XP_ROW + FREQ_MAXQ * WAVE; // doubles per wave
+// row stride of the per-wave row cache in doubles: Kp is a multiple of 4, so rows Kp apart start 8 Kp mod 128 bytes apart
+// -- for the 84 frequencies of the seeded input every fourth row on the same LDS banks; one double more makes the
+// stride odd and spreads sixteen rows over all 32 banks (lanes of different pixels add to the same column of their rows)
+#ifdef RT_FREQ_ROW_NOPAD
+__host__ __device__ constexpr int freq_row_stride(int Kp) { return Kp; }
+#else
+__host__ __device__ constexpr int freq_row_stride(int Kp) { return Kp + 1; }
+#endif
 // doubles of dynamic LDS of a work-group (layout: rt_freq_kernel)
 inline size_t freq_lds_doubles(bool iang_in_lds, int n_ang, bool exclusive, int nslot, int Kp, int wg_waves)
 {
-    const size_t per_wave = exclusive ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) Kp;
+    const size_t per_wave = exclusive ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) freq_row_stride(Kp);
     return (size_t) 2 * EXP_TAB + (iang_in_lds ? (size_t) ((n_ang + 1) & ~1) : 0) + (size_t) wg_waves * per_wave;
 }
 
@@ -883,7 +891,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     } else if (cached) {
         // LDS atomics serialise on equal addresses (the lanes of one pixel): quads whose four
         // lanes share a pixel add their values with two quad_perm DPP steps and send one atomic
-        double *my_row       = cache + (size_t) (slot >= 0 ? slot : 0) * (size_t) Kp;
+        double *my_row       = cache + (size_t) (slot >= 0 ? slot : 0) * (size_t) freq_row_stride(Kp);
         const int slot_first = __builtin_amdgcn_update_dpp(0, slot, 0x00, 0xf, 0xf, true); // quad_perm:[0,0,0,0]
         const unsigned long long same = __ballot(slot == slot_first && slot >= 0);
         const bool quad_one  = ((same >> (lane & ~3)) & 0xfull) == 0xfull;
@@ -930,8 +938,8 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
         for (int q = 0; q < n_slots; q++) {
             const int pq = __builtin_amdgcn_readlane(slot_pix, q);
             for (int k = lane; k < K; k += WAVE) {
-                const double v = cache[q * Kp + k];
-                cache[q * Kp + k] = 0.0;
+                const double v = cache[q * freq_row_stride(Kp) + k];
+                cache[q * freq_row_stride(Kp) + k] = 0.0;
 #ifdef RT_ABL_NOROWFLUSH // profiling only
                 if (v == 1234.5)
 #endif
@@ -984,7 +992,7 @@ __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_
     double *exp2_tab       = reinterpret_cast<double *>(lds_raw);
     double *lds_iang       = iang_in_lds ? exp2_tab + 2 * EXP_TAB : nullptr;
     double *waves_base     = exp2_tab + 2 * EXP_TAB + (iang_in_lds ? ((n_ang + 1) & ~1) : 0);
-    const size_t per_wave  = excl ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) H.Kp;
+    const size_t per_wave  = excl ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) freq_row_stride(H.Kp);
     double *mine           = waves_base + (size_t) (threadIdx.x >> 6) * per_wave;
     double *xpose          = mine; // (not used in exclusive mode)
     double *cache          = excl ? mine : mine + FREQ_WAVE_XPOSE;
