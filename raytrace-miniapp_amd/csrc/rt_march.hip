@@ -80,8 +80,23 @@ __device__ __forceinline__ void load_ray(const DevRays &R, unsigned ridx, rt_ray
 // Wide-argument fallbacks of the two float kernels below.  Kept out of line: inlined, the
 // double-precision libm bodies park ~40 VGPRs of polynomial coefficients across the whole
 // calling kernel for a branch that the shipped inputs never take.
-__device__ __attribute__((noinline)) float tan_wide(float x) { return (float) tan((double) x); }
-__device__ __attribute__((noinline)) float atan_wide(float x) { return (float) atan((double) x); }
+// Neither hands a NaN or an infinity to the device library's float64 routines: its f64 tangent faulted on an infinity
+// (the argument reduction indexes a table with the exponent; found by tests/test_gpu_edges.py in round 4), so the
+// non-finite cases get libm's answers here -- tan(+-inf) = tan(NaN) = NaN, atan(+-inf) = +-pi/2, atan(NaN) = NaN.
+__device__ __attribute__((noinline)) float tan_wide(float x)
+{
+    if (!(fabsf(x) <= FLT_MAX))
+        return x - x;
+    return (float) tan((double) x);
+}
+__device__ __attribute__((noinline)) float atan_wide(float x)
+{
+    if (x != x)
+        return x + x;
+    if (!(fabsf(x) <= FLT_MAX))
+        return copysignf(1.5707963705062866f, x); // (float) (pi / 2), what atanf(+-inf) returns
+    return (float) atan((double) x);
+}
 
 // The three float kernels below (ktanf_flt32 / tanf_flt32_wide / tanf_flt32_kernel, atanf_flt32_kernel) restate
 // routines of fdlibm as shipped in GNU libc 2.35 (sysdeps/ieee754/flt-32/k_tanf.c, e_rem_pio2f.c, s_atanf.c;
@@ -312,6 +327,21 @@ extern "C" __global__ void __launch_bounds__(256) rt_selftest_kernel(unsigned lo
         const float b = x / y;
         checked++;
         bad += __float_as_uint(a) != __float_as_uint(b) ? 1 : 0;
+    }
+    // the wide-argument fall-backs of the two float kernels on what the device library must never see (tan_wide /
+    // atan_wide above): non-finite arguments give libm's answers, the largest finite ones do not fault
+    if (tid == 0) {
+        float inf = __uint_as_float(0x7f800000u), qnan = __uint_as_float(0x7fc00000u), big = 3.0e38f;
+        asm volatile("" : "+v"(inf), "+v"(qnan), "+v"(big));
+        const unsigned pio2 = 0x3fc90fdbu;
+        const float t0 = tanf_flt32_kernel(inf), t1 = tanf_flt32_kernel(-inf), t2 = tanf_flt32_kernel(qnan), t3 = tan_wide(inf),
+                    t4 = tan_wide(qnan), t5 = tanf_flt32_kernel(big);
+        const float a0 = atanf_flt32_kernel(inf), a1 = atanf_flt32_kernel(-inf), a2 = atanf_flt32_kernel(qnan),
+                    a3 = atanf_flt32_kernel(big), a4 = atanf_flt32_kernel(-big);
+        checked += 11;
+        bad += (t0 == t0) + (t1 == t1) + (t2 == t2) + (t3 == t3) + (t4 == t4) + (__float_as_uint(t5) == 0x7fc12345u); // (t5: must only not fault)
+        bad += (__float_as_uint(a0) != pio2) + (__float_as_uint(a1) != (pio2 | 0x80000000u)) + (a2 == a2) +
+               (__float_as_uint(a3) != pio2) + (__float_as_uint(a4) != (pio2 | 0x80000000u));
     }
     atomicAdd(&counts[0], checked);
     atomicAdd(&counts[1], bad);
@@ -573,7 +603,6 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
             }
         }
         if (more && (n_idle >= REFILL)) {
-            spin = 0;
             const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (idle >> 32),
                                                              __builtin_amdgcn_mbcnt_lo((unsigned) idle, 0u));
             int need = n_idle, off = 0;
@@ -632,6 +661,11 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 need -= take;
                 off += take;
             }
+            // (the watchdog restarts only when the wave really took rays: a refill that hands out nothing -- the ray
+            // counters dry for this wave, or, FUSED, all 32 tile slots held open by tiles with a ray that does not
+            // advance -- must not keep resetting it, or a wave with eight idle lanes would never reach the limit)
+            if (!BOUNDED && __ballot(got) != 0ull)
+                spin = 0;
             if (got) {
                 // Helper.h:404-418
                 rt_ray ray;

@@ -115,6 +115,12 @@ void rtr::plan_quiesce(rt_hip_plan *p)
         if (hipStreamSynchronize(p->last_stream) != hipSuccess)
             (void) hipGetLastError(); // a caller's stream that is gone: nothing is in flight on it
     }
+    // a run that failed after its first enqueue (rt_hip_plan_run): zeroing kernel, memsets or march slices may still be
+    // writing the plan's blocks on that queue
+    if (p && p->queued && !(p->ran && p->queued_stream == p->last_stream)) {
+        if (hipStreamSynchronize(p->queued_stream) != hipSuccess)
+            (void) hipGetLastError();
+    }
 }
 
 extern "C" {
@@ -872,6 +878,9 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     int rc = plan_prepare_probe(p);
     if (rc != RT_OK)
         return rc;
+    // from here on work is queued: whatever happens below, destroy / quiesce must wait for this queue
+    p->queued_stream = stream;
+    p->queued        = true;
     if (p->probe_on && p->n_rays)
         HIP_TRY(hipMemsetAsync(p->probe, 0, (size_t) p->n_rays * (sizeof(rt_ray) + 8), stream));
     static_assert(sizeof(rt::DevCtl) % 8 == 0 && alignof(rt::DevCtl) >= 8, "zeroed in 8-byte words");
@@ -898,6 +907,7 @@ int rt_hip_plan_run(rt_hip_plan *p, void *stream_v, double *image_dev, double *i
     p->last_image  = image_dev;
     p->last_iang   = iang_dev;
     p->ran         = true;
+    p->queued      = false; // (`ran` + last_stream cover it from here)
     p->repeated    = false;
     p->out_staged  = false;
     return RT_OK;

@@ -53,6 +53,10 @@ struct rt_hip_plan {
     // last run
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
+    // the queue a run has put work on, set BEFORE its first enqueue: a run that fails midway (a launch error, an
+    // allocation) leaves `ran` as it was, and plan_quiesce still has to wait for what was already queued
+    hipStream_t queued_stream = nullptr;
+    bool queued = false;
     double *last_image = nullptr, *last_iang = nullptr;
     bool ran = false;
     // timing ring (rt_hip_plan_set_timing_ring): event triples of the last runs, so that a caller can time

@@ -230,6 +230,19 @@ q.beam.b = q.beam.db * (np.arange(5) - 2.0)
 with hip.Plan(q) as plan:
     out = plan.set_ray_grid().run().fetch()
     print("GRID", out["failure_code"], out["stats"]["n_rays"], plan.last_fused(), flush=True)
+# slot exhaustion of the one-launch run (ADVICE round 4): 64 launch angles per pixel, (0, 0) among them, so that EVERY
+# 64-ray tile holds exactly one ray that never advances; one wave per work-group and 40 tiles per wave, so that all 32
+# tile slots of a wave end up held open by such tiles while eight or more of its lanes are idle -- refills that hand
+# out nothing must not restart the watchdog
+import os
+os.environ["RT_HIP_MARCH_THREADS"] = "64"
+q = pm.regrid_beam(p, nx=160, ny=64)                   # 10 240 pixels = tiles: 40 per wave on 256 CUs
+q.beam.a = q.beam.da * (np.arange(8) - 4.0)
+q.beam.b = q.beam.db * (np.arange(8) - 4.0)
+with hip.Plan(q) as plan:
+    out = plan.set_ray_grid().run().fetch()
+    print("SLOTS", out["failure_code"], out["stats"]["n_rays"], plan.last_fused(), flush=True)
+del os.environ["RT_HIP_MARCH_THREADS"]
 # and the library is fine afterwards
 ok = hip.image_loop(base)
 print("AFTER", ok["failure_code"], ok["stats"]["cell_steps"], flush=True)
@@ -252,6 +265,8 @@ def test_a_ray_that_never_advances_is_given_up_not_marched_for_ever():
     assert "LIST 2 3 0.0" in r.stdout, r.stdout
     grid = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("GRID")][0]
     assert int(grid[1]) & 2 and int(grid[2]) > 0, r.stdout
+    slots = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("SLOTS")][0]
+    assert int(slots[1]) & 2 and int(slots[2]) >= 32 * 64 * 256 and slots[3] == "True", r.stdout
     assert "AFTER 0 4768067" in r.stdout, r.stdout
 
 
