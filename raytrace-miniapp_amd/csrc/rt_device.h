@@ -210,6 +210,13 @@ struct DevParams {
     // (RayTraceImageCPU.cpp:29-36); after the repeat so does this image.  0 = the normal pass.
     unsigned int safe;
     unsigned int park; // march: lanes that must wait for block [A] before it runs (rt_march.hip); 1 = every iteration
+    // march, express waves (rt_march.hip): a wave that holds a ray older than express_age loop iterations raises its
+    // wave priority (0 = never); with express_hold it also fetches no further rays from the launch's counters while it
+    // holds such a ray, so that it thins out and its iterations get shorter
+    unsigned int express_age, express_hold, express_park, express_tail;
+    // the last late_chunks chunks of a march launch are handed out to the first late_waves waves of each work-group only
+    // (rt_march.hip, "The end of a launch"); 0: no such zone
+    unsigned int late_chunks, late_waves;
     unsigned char *bad; // [n_rays], only in the repeat
 };
 

@@ -36,13 +36,18 @@ namespace rt {
 //   [0, blob_bytes)            march tables; after the last marching wave: transposition buffers n_free .. n_waves-1
 //   off_exp                    [2][EXP_TAB] doubles
 //   off_iang                   I_ang histogram, n_ang doubles rounded up to even
-//   off_ctl                    4 words: list head | marching waves | next buffer | -
+//   off_ctl                    4 words: list head | marching waves | next buffer | list nodes handed out
 //   off_rem                    [n_waves][32] words: rays in flight of every wave's open tiles (rt_march.hip, march_wave)
+//   off_nodes                  [node_cap][2] words: the nodes of the tile list (rt_march.hip, TileList)
 //   off_buf                    transposition buffers 0 .. n_free-1, per_wave doubles each
 struct FusedLay {
-    unsigned off_exp, off_iang, off_ctl, off_rem, off_buf;
+    unsigned off_exp, off_iang, off_ctl, off_rem, off_nodes, off_buf;
+    unsigned node_cap;
     unsigned n_free, per_wave; // per_wave in doubles
     unsigned split, k_part;    // TileList::split, TileList::k_part
+    // the last n_consumers waves of a work-group never march: they run the frequency pass of finished tiles from the
+    // start of the launch, so that the frequency work overlaps the march instead of piling up behind it (0: none)
+    unsigned n_consumers, consumers_first;
 };
 struct FusedKArg {
     DevParams P;
@@ -65,7 +70,11 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     double *lds_iang   = reinterpret_cast<double *>(lds_raw + A.lay.off_iang);
     unsigned *ctl      = reinterpret_cast<unsigned *>(lds_raw + A.lay.off_ctl);
     double *buf_free   = reinterpret_cast<double *>(lds_raw + A.lay.off_buf);
-    const unsigned n_waves = blockDim.x >> 6;
+    const unsigned n_waves  = blockDim.x >> 6;
+    const unsigned n_march  = n_waves - A.lay.n_consumers; // waves 0 .. n_march-1 march, the others only consume
+    // (which waves: the instruction arbiter of a SIMD serves its OLDEST waves first -- the lowest wave numbers of the
+    // work-group -- whatever s_setprio says; consumers_first makes the consumers those waves)
+    const bool consumer     = A.lay.consumers_first ? (threadIdx.x >> 6) < A.lay.n_consumers : (threadIdx.x >> 6) >= n_march;
     // (everything below lies behind the march tables: the copy of the tables at the head of march_wave ends in the
     // barrier that also publishes these)
     for (unsigned c = threadIdx.x; c < A.lay.n_free * A.lay.per_wave; c += blockDim.x)
@@ -79,17 +88,21 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         lds_iang[c] = 0.0;
     if (threadIdx.x == 0) {
         ctl[0] = TILE_NONE;
-        ctl[1] = n_waves;
+        ctl[1] = n_march;
         ctl[2] = 0u;
+        ctl[3] = 0u;
     }
-    const TileList list{ &ctl[0], A.tile_next, reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + (threadIdx.x >> 6) * 32u,
-                         &ctl[1], n_waves, A.lay.split, A.lay.k_part };
+    const TileList list{ &ctl[0], A.tile_next, reinterpret_cast<unsigned *>(lds_raw + A.lay.off_nodes), &ctl[3], A.lay.node_cap,
+                         reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + (threadIdx.x >> 6) * 32u,
+                         &ctl[1], n_march, A.lay.split, A.lay.k_part };
 
     // ---- phase 1: the march (rt_march.hip), one tile per chunk, finished tiles pushed onto the list ----
     // (marching waves given a higher wave priority than the waves of their SIMD that have turned to the frequency pass
     // -- so that the stragglers with the long rays finish sooner: measured, s_setprio 1 and 3, nothing: 2.66 / 2.65
     // against 2.65 ms, 8-rank shard 0.537 / 0.536 against 0.534; profiles/r04_prio_ab.txt)
-    march_wave<true, BOUNDED, true>(A.P, lds_raw, list);
+    march_load_tables<true>(A.P, lds_raw);
+    if (!consumer)
+        march_wave<true, BOUNDED, true>(A.P, lds_raw, list);
 
     // ---- phase 2: this wave's rays have run out; frequency pass on the work-group's finished tiles ----
     const int lane = lane_id();
@@ -99,7 +112,8 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
 #endif
     unsigned slot  = 0;
     if (lane == 0) {
-        __hip_atomic_fetch_add(&ctl[1], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // one marching wave less
+        if (!consumer)
+            __hip_atomic_fetch_add(&ctl[1], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // one marching wave less
         slot = __hip_atomic_fetch_add(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     slot = (unsigned) __builtin_amdgcn_readfirstlane((int) slot);

@@ -263,6 +263,22 @@ int plan_repeat_checked(rt_hip_plan *p)
     return RT_OK;
 }
 
+// The chunks at the end of the ray list that only the oldest wave of every SIMD takes (rt_march.hip, "The end of a
+// launch"): about as many rays as those waves march in one drain period, RT_HIP_LATE_X10 tenths of a ray per lane of
+// theirs (0: no such zone), at most a quarter of the launch.
+static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg)
+{
+    const unsigned x10   = env_unsigned("RT_HIP_LATE_X10", 32, 0, 1000);
+    const unsigned waves = env_unsigned("RT_HIP_LATE_WAVES", 4, 0, 16);
+    p->P.late_waves  = waves < waves_per_wg ? waves : waves_per_wg;
+    p->P.late_chunks = 0;
+    if (x10 == 0 || p->P.late_waves == 0 || p->P.chunk == 0)
+        return;
+    unsigned long long rays = (unsigned long long) grid * p->P.late_waves * 64ull * x10 / 10ull;
+    rays                    = rays > p->n_rays / 4 ? p->n_rays / 4 : rays;
+    p->P.late_chunks        = (unsigned) (rays / p->P.chunk);
+}
+
 // One run on a queue: the march (persistent lanes) -> one record per ray -> the frequency pass, as ONE launch
 // (rt_fused.hip) where that applies, as two kernels otherwise (or the path tracer in place of the frequency kernel).
 int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
@@ -283,8 +299,24 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     // global variant (persistent 256-thread work-groups) when the blob does not fit (RT_HIP_MARCH=global forces it)
     const char *force   = getenv("RT_HIP_MARCH");
     const bool lds_tab  = p->P.blob_bytes + 8 * 1024 <= p->lds_limit && !(force && strcmp(force, "global") == 0);
+    // A run is one march launch -- or three, when the ray list is still on the host
+    // (rt_hip_image_loop): the list crosses PCIe in slices, each with a synchronous copy (the fast
+    // pageable path, ~35 GB/s; asynchronous copies of pageable memory reach a third of that), and
+    // the march of a slice runs on image_loop's non-blocking queue while the host copies the next
+    // one (16 B/ray: 102 MB, ~3 ms for the 6.4 M-ray case; swept: 3 slices 5.8 ms, 1 slice 6.9, 8 slices 7.3).
+    unsigned n_launch = (p->host_rays && p->n_rays >= (2ull << 20)) ? 3u : 1u;
+    if (p->host_rays)
+        n_launch = env_unsigned("RT_HIP_UPLOAD_SLICES", n_launch, 1, 8); // tuning
+    n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
+    // ---- the whole path in ONE launch (rt_fused.hip) where it applies: emission mode on the beam's own ray grid
+    // with at least 32 rays per pixel (a 64-ray tile then spans at most three pixels: the few-runs deposit, which
+    // needs no row cache), tables in LDS, nothing that wants the march records to itself (probe, path tracer,
+    // the checking repeat, profiling switches), and room in LDS for the frequency pass beside the tables
+    const bool fused_cand = lds_tab && n_launch == 1 && p->n_rays > 0 && !p->path_on && !p->probe_on && p->P.debug == 0 && p->P.use_emis &&
+                            !p->P.exclusive && p->P.safe == 0 && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32 &&
+                            p->n_iang * sizeof(double) <= 32 * 1024 && env_unsigned("RT_HIP_FUSED", 1, 1, 2) == 1;
     unsigned bthr = lds_tab ? 1024u : 256u;
-    if (lds_tab) {
+    if (lds_tab && !fused_cand) {
         // Few rays per lane leave the persistent lanes waiting for the longest ray of a short
         // queue: below about three rays per lane, fewer and busier lanes win (ASE_small, 399 000
         // rays on 256 CUs: 0.65 ms with 1024 threads per CU, 0.44 ms with 512; 8 waves per CU is
@@ -294,6 +326,9 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
         // 0.472 with 1024; 4156 per CU: equal; 1558 per CU: 0.376 ms with 512, 0.432 with 1024)
         bthr = per_cu_rays >= 4ull * 1024 ? 1024u : (per_cu_rays >= 2560ull ? 768u : 512u);
     }
+    // (the one-launch run always takes sixteen waves per CU: a quarter of them run the frequency pass from the start and
+    // the end of the ray list is kept for the oldest wave of every SIMD, see below -- with those two the full
+    // work-group wins at every size measured, 399 K rays ... 6.4 M, profiles/r05_fused_end.txt)
     bthr = env_unsigned("RT_HIP_MARCH_THREADS", bthr, 64, lds_tab ? 1024 : 256) / 64 * 64; // occupancy experiments
     const size_t mlds   = lds_tab ? (size_t) p->P.blob_bytes : 0;
     int per_cu          = 0;
@@ -331,6 +366,10 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     // lanes that must wait for block [A] of the march before it runs (swept 1 ... 40 on the 6.4 M-ray
     // stand-in: 2.36 ms at 1, flat optimum 2.12 ms at 8 ... 24, 2.63 ms at 40)
     p->P.park    = env_unsigned("RT_HIP_MARCH_PARK", 12, 1, 64);
+    p->P.express_age  = env_unsigned("RT_HIP_EXPRESS_AGE", 0, 0, 1u << 20);
+    p->P.express_hold = env_unsigned("RT_HIP_EXPRESS_HOLD", 0, 0, 1);
+    p->P.express_park = env_unsigned("RT_HIP_EXPRESS_PARK", 0, 0, 64);
+    p->P.express_tail = env_unsigned("RT_HIP_EXPRESS_TAIL", 0, 0, 2);
     p->P.path_on = p->path_on ? 1u : 0u;
     p->P.spin_limit = env_unsigned("RT_HIP_MARCH_SPIN_LIMIT", 1u << 24, 1024, 0x7fffffffu); // (tests lower it)
     p->P.no_skip = p->gv_has_nan ? 1u : 0u; // the CPU loop multiplies 0 * gv[row 0] for sub-segments a ray never entered
@@ -351,23 +390,10 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
         p->P.path_err = p->path_err;
     }
     HIP_TRY(hipEventRecord(p->ev0, stream));
-    // A run is one march launch -- or three, when the ray list is still on the host
-    // (rt_hip_image_loop): the list crosses PCIe in slices, each with a synchronous copy (the fast
-    // pageable path, ~35 GB/s; asynchronous copies of pageable memory reach a third of that), and
-    // the march of a slice runs on image_loop's non-blocking queue while the host copies the next
-    // one (16 B/ray: 102 MB, ~3 ms for the 6.4 M-ray case; swept: 3 slices 5.8 ms, 1 slice 6.9, 8 slices 7.3).
-    unsigned n_launch = (p->host_rays && p->n_rays >= (2ull << 20)) ? 3u : 1u;
-    if (p->host_rays)
-        n_launch = env_unsigned("RT_HIP_UPLOAD_SLICES", n_launch, 1, 8); // tuning
-    n_launch = n_launch < 1 ? 1 : (n_launch > 8 ? 8 : n_launch);
-    // ---- the whole path in ONE launch (rt_fused.hip) where it applies: emission mode on the beam's own ray grid
-    // with at least 32 rays per pixel (a 64-ray tile then spans at most three pixels: the few-runs deposit, which
-    // needs no row cache), tables in LDS, nothing that wants the march records to itself (probe, path tracer,
-    // the checking repeat, profiling switches), and room in LDS for the frequency pass beside the tables
     p->last_fused = false;
-    if (lds_tab && n_launch == 1 && grid > 0 && !p->path_on && !p->probe_on && p->P.debug == 0 && p->P.use_emis &&
-        !p->P.exclusive && p->P.safe == 0 && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32 &&
-        p->n_iang * sizeof(double) <= 32 * 1024 && env_unsigned("RT_HIP_FUSED", 1, 1, 2) == 1) {
+    p->P.late_chunks = 0;
+    p->P.late_waves  = 0;
+    if (fused_cand && grid > 0) {
         const unsigned nw       = bthr / 64;
         // doubles per wave: transposition rows + window totals of the few-runs deposit for 2 pixel runs per tile (a pixel
         // has at least 64 rays) or 3, no row cache
@@ -378,7 +404,18 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
         lay.off_iang = lay.off_exp + 2u * rt::EXP_TAB * (unsigned) sizeof(double);
         lay.off_ctl  = lay.off_iang + (unsigned) (((p->n_iang + 1) & ~(size_t) 1) * sizeof(double));
         lay.off_rem  = lay.off_ctl + 16u;
-        lay.off_buf  = lay.off_rem + nw * 32u * (unsigned) sizeof(unsigned);
+        lay.off_nodes = lay.off_rem + nw * 32u * (unsigned) sizeof(unsigned);
+        // nodes of the work-group's tile list in LDS: room for twice a work-group's share of the entries (a tile is one
+        // entry, a split tile four; a work-group that marches faster owes more), within 64 ... 1024; the surplus of a
+        // work-group that pushes more takes the global links
+        {
+            const unsigned long long wgs = (p->n_rays + bthr - 1) / bthr < (unsigned long long) p->cu_count ? (p->n_rays + bthr - 1) / bthr
+                                                                                                          : (unsigned long long) p->cu_count;
+            unsigned long long cap = wgs ? 2ull * ((unsigned long long) p->P.n_tiles / wgs + 1) + 32 : 64;
+            cap           = cap < 64 ? 64 : (cap > 1024 ? 1024 : cap);
+            lay.node_cap  = env_unsigned("RT_HIP_FUSED_NODES", (unsigned) cap, 0, 4096);
+        }
+        lay.off_buf  = (unsigned) align_up(lay.off_nodes + lay.node_cap * 2u * (unsigned) sizeof(unsigned), 16);
         lay.per_wave = (unsigned) per_wave;
         const size_t room = p->lds_limit > lay.off_buf ? (p->lds_limit - lay.off_buf) / (per_wave * sizeof(double)) : 0;
         lay.n_free        = (unsigned) (room < nw ? room : nw);
@@ -391,6 +428,11 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
             const unsigned split_env = env_unsigned("RT_HIP_FUSED_SPLIT", 1, 1, 3);
             lay.split  = split_env == 2 ? 0u : (split_env == 3 ? 2u : 1u);
             lay.k_part = p->P.K >= 32 ? (unsigned) (((p->P.K + 3) / 4 + 3) / 4 * 4) : 0u;
+            // a quarter of the work-group -- its last, youngest waves, one per SIMD -- never marches (rt_fused.hip)
+            lay.n_consumers = env_unsigned("RT_HIP_FUSED_CONSUMERS", nw / 4, 0, nw > 1 ? nw - 1 : 0);
+            if (lay.n_consumers >= nw)
+                lay.n_consumers = nw - 1;
+            lay.consumers_first = env_unsigned("RT_HIP_FUSED_CONSUMERS_FIRST", 0, 0, 1);
             if (p->tile_next_n < n_tiles || !p->tile_next) {
                 plan_quiesce(p);
                 pool_free(p->device, p->tile_next);
@@ -403,6 +445,7 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
             p->P.launch_id = 0;
             p->P.chunk     = (p->P.chunk + 32) / 64 * 64; // whole tiles per reservation (64 ... 192 rays)
             p->P.chunk     = p->P.chunk < 64 ? 64 : p->P.chunk;
+            late_zone(p, (unsigned) ((p->n_rays + bthr - 1) / bthr < (unsigned long long) p->cu_count ? (p->n_rays + bthr - 1) / bthr : p->cu_count), nw);
             p->P.tile_begin = 0;
             p->P.tile_end   = p->P.n_tiles;
             p->P.freq_id    = 0;
@@ -491,6 +534,33 @@ int rt_hip_debug_wavetimes(unsigned long long *summary8, unsigned long long *end
     HIP_TRY(hipMemcpyFromSymbol(dry8192, HIP_SYMBOL(rt::g_wt_dry), 8192 * sizeof(unsigned long long)));
     unsigned long long init[8] = { ~0ull, 0, ~0ull, 0, ~0ull, 0, 0, 0 };
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wt), init, sizeof(init)));
+    return RT_OK;
+}
+// the march trace of every wave (rt_march.hip: g_wt_trace), then cleared
+int rt_hip_debug_wavetrace(unsigned long long *trace, int samples, unsigned *blocks)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    if (samples != rt::WT_TRACE)
+        return fail_arg("rt_hip_debug_wavetrace: samples");
+    if (blocks)
+        HIP_TRY(hipMemcpyFromSymbol(blocks, HIP_SYMBOL(rt::g_wt_blocks), sizeof(unsigned) * 8192 * rt::WT_TRACE * 6));
+    HIP_TRY(hipMemcpyFromSymbol(trace, HIP_SYMBOL(rt::g_wt_trace), sizeof(unsigned long long) * 8192 * rt::WT_TRACE));
+    void *sym = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(rt::g_wt_trace)));
+    HIP_TRY(hipMemset(sym, 0, sizeof(unsigned long long) * 8192 * rt::WT_TRACE));
+    return RT_OK;
+}
+// time in tile_publish per wave (rt_march.hip: g_wt_pub, g_wt_vm), then cleared
+int rt_hip_debug_publish(unsigned long long *pub4, unsigned long long *vm)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(pub4, HIP_SYMBOL(rt::g_wt_pub), sizeof(unsigned long long) * 8192 * 4));
+    HIP_TRY(hipMemcpyFromSymbol(vm, HIP_SYMBOL(rt::g_wt_vm), sizeof(unsigned long long) * 8192));
+    void *sym = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(rt::g_wt_pub)));
+    HIP_TRY(hipMemset(sym, 0, sizeof(unsigned long long) * 8192 * 4));
+    HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(rt::g_wt_vm)));
+    HIP_TRY(hipMemset(sym, 0, sizeof(unsigned long long) * 8192));
     return RT_OK;
 }
 // ... and of the LAST frequency launch: times[6][8192] = {start, tables ready, first tile done, last tile done, where, tiles} per wave

@@ -393,14 +393,30 @@ __device__ unsigned short g_ray_iters[1u << 23]; // diagnostic: loop iterations 
 #ifdef RT_WAVETIMES // diagnostic: start / counters-dry / end time of every wave of the last launch (100 MHz clock)
 __device__ unsigned long long g_wt[8];
 __device__ unsigned long long g_wt_end[8192], g_wt_dry[8192];
+// ... and a trace of every wave's march: every 16th loop iteration {100 MHz time | live lanes << 40 | runs of [A] in
+// the last 16 iterations << 48 | runs of [B] << 56}, up to 64 samples; [wave][0] = samples written
+constexpr int WT_TRACE = 64;
+__device__ unsigned long long g_wt_trace[8192][WT_TRACE];
+// shader-clock cycles of the last 16 iterations spent in {refill + loop head, [A1], [A2], retire + publish, [B], [C]}
+__device__ unsigned g_wt_blocks[8192][WT_TRACE][6];
 #endif
 // Work-group list of finished tiles of the fused kernel (rt_fused.hip): a wave that has marched all 64 rays of a
 // chunk -- one tile of the frequency pass -- pushes the tile number; waves whose rays have run out pop tiles and run
 // their frequency pass.  A lock-free stack: the head is an LDS word, the links are one word per tile in global
 // memory (`next`); tiles are pushed once and never pushed again, so a pop cannot meet a recycled node.
 struct TileList {
-    unsigned *head; // LDS
-    unsigned *next; // global, [4 n_tiles]: link of list entry (tile, part) at 4 tile + part
+    unsigned *head; // LDS: reference of the top node, TILE_NONE when empty
+    unsigned *next; // global, [4 n_tiles]: link of list entry (tile, part) at 4 tile + part (overflow nodes only)
+    // The nodes live in LDS: node i = {entry, link} at lnode[2 i], i handed out once by the counter *nalloc and never
+    // again (so a pop cannot meet a recycled node); LDS operations of a wave execute in order, so a push is
+    // write-entry, write-link, compare-exchange with no waiting in between.  (Round 4 kept the links in global memory:
+    // every attempt of a push then waited for a store to complete -- microseconds under load -- and failed whenever
+    // another wave had popped meanwhile: tools/wave_trace.py showed single pushes of up to 100 us, with the 64 lanes of a
+    // marching wave standing still behind them.)  A work-group that pushes more than `cap` entries puts the surplus on
+    // the same stack with global links, as before: a reference with bit 31 set is such an entry.
+    unsigned *lnode;  // LDS, [cap][2]
+    unsigned *nalloc; // LDS
+    unsigned cap;
     unsigned *rem;  // LDS, [32] per wave: rays of the wave's tiles in flight that have not retired yet
     unsigned *marching; // LDS: waves of the work-group that have not left the march yet
     unsigned n_waves;   // of the work-group
@@ -416,15 +432,37 @@ __device__ __forceinline__ unsigned tile_node(unsigned entry)
 {
     return (entry & TILE_ID_MASK) * 4u + ((entry & TILE_PART_FLAG) ? (entry >> TILE_PART_SHIFT) & 3u : 0u);
 }
+#ifdef RT_WAVETIMES
+__device__ unsigned long long g_wt_pub[8192][4]; // per wave: {ticks in tile_publish, pushes, failed compare-exchanges, longest publish}
+__device__ unsigned long long g_wt_vm[8192]; // ticks waiting for the record stores before a publish
+#endif
 // one lane of the calling wave executes these
+constexpr unsigned TILE_REF_GLOBAL = 1u << 31;
 __device__ __forceinline__ void tile_push(const TileList &T, unsigned tile)
 {
-    unsigned old = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned id = __hip_atomic_fetch_add(T.nalloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned old      = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (id < T.cap) {
+        __hip_atomic_store(&T.lnode[2u * id], tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (;;) {
+            __hip_atomic_store(&T.lnode[2u * id + 1u], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (entry and link are in LDS before the head can name the node)
+            if (__hip_atomic_compare_exchange_strong(T.head, &old, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                return;
+#ifdef RT_WAVETIMES
+            g_wt_pub[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u][2]++;
+#endif
+        }
+    }
+    tile |= TILE_REF_GLOBAL;
     for (;;) {
-        __hip_atomic_store(&T.next[tile_node(tile)], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (pushed and popped by waves of one work-group)
+        __hip_atomic_store(&T.next[tile_node(tile & ~TILE_REF_GLOBAL)], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (pushed and popped by waves of one work-group)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the link is in memory before the head can name the tile
         if (__hip_atomic_compare_exchange_strong(T.head, &old, tile, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
             return;
+#ifdef RT_WAVETIMES
+        g_wt_pub[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u][2]++;
+#endif
     }
 }
 // a finished tile: whole, or in four parts when the work-group is down to its last marching waves (an eighth of them)
@@ -447,34 +485,25 @@ __device__ __forceinline__ unsigned tile_pop(const TileList &T)
 {
     unsigned old = __hip_atomic_load(T.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (old != TILE_NONE) {
-        const unsigned nxt = __hip_atomic_load(&T.next[tile_node(old)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned nxt = (old & TILE_REF_GLOBAL)
+                                 ? __hip_atomic_load(&T.next[tile_node(old & ~TILE_REF_GLOBAL)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                 : __hip_atomic_load(&T.lnode[2u * old + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__hip_atomic_compare_exchange_strong(T.head, &old, nxt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
             break;
     }
-    return old;
+    if (old == TILE_NONE)
+        return TILE_NONE;
+    // the entry the node carries (an LDS node's entry word never changes once the node is on the list)
+    return (old & TILE_REF_GLOBAL) ? (old & ~TILE_REF_GLOBAL) : __hip_atomic_load(&T.lnode[2u * old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // The march of one wave over the rays of a launch.  FUSED (rt_fused.hip): the reserved chunks are whole 64-ray tiles
 // (P.ray_begin = 0, P.chunk a multiple of 64) and are handed to the lanes tile by tile; every tile in flight has a
 // counter of its rays that have not retired (done.rem, one of 32 slots of this wave), and the wave pushes the tile
 // onto `done` when the counter reaches zero and all its record stores have landed.
-template <bool LDS_TAB, bool BOUNDED, bool FUSED>
-__device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *lds_raw, const TileList done)
+// ---- tables: copy the march blob to LDS once per work-group (every wave of the work-group takes part; ends in a barrier) ----
+template <bool LDS_TAB> __device__ __forceinline__ void march_load_tables(const DevParams &P, unsigned char *lds_raw)
 {
-    const int lane        = lane_id();
-    const int L           = P.L;
-    const int S           = L * RT_N_SUB;
-    const unsigned n_rays = P.ray_end; // this launch marches rays [P.ray_begin, P.ray_end)
-    const bool backward   = P.method == 1;
-    const bool use_emis   = P.use_emis != 0;
-    const unsigned CH     = P.chunk;
-#ifndef RT_REFILL
-#define RT_REFILL 8
-#endif
-    const int REFILL      = RT_REFILL; // refill when this many lanes are idle (or the wave is empty)
-
-    // ---- tables: copy the march blob to LDS once per work-group ----
-    const unsigned char *tab;
     if (LDS_TAB) {
         // (eight 16-byte loads in flight per lane: the copy of a ~100 KB blob costs one L2 round trip,
         // not one per 16 KB pass of the work-group)
@@ -496,10 +525,26 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
             }
         }
         __syncthreads();
-        tab = lds_raw;
-    } else {
-        tab = P.blob;
     }
+}
+
+template <bool LDS_TAB, bool BOUNDED, bool FUSED>
+__device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *lds_raw, const TileList done)
+{
+    const int lane        = lane_id();
+    const int L           = P.L;
+    const int S           = L * RT_N_SUB;
+    const unsigned n_rays = P.ray_end; // this launch marches rays [P.ray_begin, P.ray_end)
+    const bool backward   = P.method == 1;
+    const bool use_emis   = P.use_emis != 0;
+    const unsigned CH     = P.chunk;
+#ifndef RT_REFILL
+#define RT_REFILL 8
+#endif
+    const int REFILL      = RT_REFILL; // refill when this many lanes are idle (or the wave is empty)
+
+    // ---- tables: the march blob, in LDS (copied by march_load_tables, which the caller has run) or in place ----
+    const unsigned char *tab = LDS_TAB ? lds_raw : P.blob;
     const BlobGain *hdr = reinterpret_cast<const BlobGain *>(tab);
     // LDS byte address of the blob, for the hand-written reads of block [A2]
     const unsigned lds_base = LDS_TAB ? (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) lds_raw : 0u;
@@ -524,6 +569,17 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     const unsigned n_launch_rays = n_rays - P.ray_begin;
     const unsigned n_chunks      = (n_launch_rays + CH - 1) / CH;
     unsigned shard = blockIdx.x & 7u, shards_seen_empty = 0;
+    // The end of a launch.  The last rays handed out set when the march ends -- their length times the time of an
+    // iteration -- and the instruction arbiter of a SIMD serves its oldest waves first (tools/wave_trace.py: the
+    // marching waves that stall for 100 us while the rest of their SIMD runs the frequency pass are the highest wave
+    // numbers of their work-group, whatever s_setprio says).  So the last P.late_chunks chunks of the list are kept for
+    // the first P.late_waves waves of each work-group, the oldest wave of every SIMD: the other waves see the counters
+    // dry that much earlier, drain and turn to the frequency pass while the old waves are still busy, and the final
+    // drain is run by one wave per SIMD that nothing on its SIMD outranks.  Zone 0: chunks [0, n_main), zone 1: the rest,
+    // with counters of its own (next_tile[..][shard][8]).
+    const unsigned n_main = n_chunks - (P.late_chunks < n_chunks ? P.late_chunks : 0u);
+    const bool late_wave  = (threadIdx.x >> 6) < P.late_waves;
+    unsigned zone = 0;
 
     // ---- per-lane state ----
     int st        = ST_IDLE;
@@ -558,17 +614,29 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     Inst inst;
 #endif
 
-#ifdef RT_TIMEBLOCKS
+#if defined(RT_TIMEBLOCKS) || defined(RT_WAVEBLOCKS)
     unsigned long long tb_acc[6] = { 0, 0, 0, 0, 0, 0 }, tb_last = __builtin_readcyclecounter(), tb_iters = 0;
 #endif
 #ifdef RT_WAVETIMES
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long wt_dry = 0;
+    unsigned wt_a_runs = 0, wt_b_runs = 0;
 #endif
 #ifdef RT_INSTRUMENT
     unsigned ray_iters = 0;
 #endif
     unsigned spin = 0; // (BOUNDED = false only)
+    // Express waves.  A launch cannot end before its longest ray has taken its last step, and a ray's steps are
+    // sequential: what the launch can do is run the waves that hold the old rays FAST.  `wave_iter` counts this wave's
+    // loop iterations, `born` is its value when the lane took its ray; a wave that holds a ray older than P.express_age
+    // iterations raises its priority (the instruction arbiter of a SIMD serves priority before age, MI355X_MICROARCH.md)
+    // and, with P.express_hold, stops fetching rays from the counters while it does: its short rays retire, fewer lanes
+    // mean fewer of the three blocks per iteration, and the long rays it holds advance at the pace of a wave that has
+    // its SIMD to itself.  Looked at every fourth iteration; everything here is wave-uniform.
+    unsigned wave_iter = 0, born = 0;
+    bool old_wave = false;
+    if (P.express_tail == 1u)
+        __builtin_amdgcn_s_setprio(2);
     for (;;) {
         RT_MARK(5); // [C] of the previous iteration
 #ifdef RT_INSTRUMENT
@@ -582,6 +650,36 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         const int n_idle              = (int) __popcll(idle);
         if (n_idle == WAVE && !more)
             break;
+        wave_iter++;
+#ifdef RT_WAVETIMES
+        if ((wave_iter & 15u) == 0u) {
+            const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), smp = wave_iter >> 4;
+            if (lane == 0 && wid < 8192u && smp < (unsigned) WT_TRACE) {
+                g_wt_trace[wid][smp] = (__builtin_amdgcn_s_memrealtime() & 0xffffffffffull) | ((unsigned long long) (WAVE - n_idle) << 40) |
+                                       ((unsigned long long) wt_a_runs << 48) | ((unsigned long long) wt_b_runs << 56);
+                g_wt_trace[wid][0] = smp;
+#ifdef RT_WAVEBLOCKS
+                for (int b = 0; b < 6; b++)
+                    g_wt_blocks[wid][smp][b] = (unsigned) tb_acc[b];
+#endif
+            }
+#ifdef RT_WAVEBLOCKS
+            for (int b = 0; b < 6; b++)
+                tb_acc[b] = 0;
+#endif
+            wt_a_runs = wt_b_runs = 0;
+        }
+#endif
+        if (P.express_age != 0u && (wave_iter & 3u) == 0u) {
+            const bool o = __ballot(st != ST_IDLE && wave_iter - born > P.express_age) != 0ull;
+            if (o != old_wave) {
+                old_wave = o;
+                if (o)
+                    __builtin_amdgcn_s_setprio(3);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
+        }
         // Watchdog of the instance that takes tables and step sizes as they come (BOUNDED = false: something is outside
         // the ranges rt_hip_plan_create verifies -- an index far from 1, a gradient beyond 1e12, a dz beyond 1e6 cm).
         // The reference's loops have no iteration limit, and with such inputs a ray's steps can stop advancing (an
@@ -609,6 +707,8 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
             bool got = false;
             while (need > 0) {
                 if (chunk_next == chunk_end && !(FUSED && chunk_next != fetched_end)) {
+                    if (old_wave && P.express_hold != 0u)
+                        break; // an express wave takes no new reservation (what it has reserved it still hands out)
                     unsigned c = 0;
 #ifdef RT_MARCH_ONE_COUNTER // experiment: one counter for all waves
                     if (lane == 0)
@@ -617,12 +717,19 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                     shards_seen_empty = 7;
 #else
                     if (lane == 0)
-                        c = atomicAdd(&P.ctl->next_tile[P.launch_id][shard][0], 1u);
-                    c = (unsigned) __builtin_amdgcn_readfirstlane((int) c) * 8u + shard; // chunk number
+                        c = atomicAdd(&P.ctl->next_tile[P.launch_id][shard][zone * 8u], 1u);
+                    c = (unsigned) __builtin_amdgcn_readfirstlane((int) c) * 8u + shard + zone * n_main; // chunk number
 #endif
-                    if (c >= n_chunks) { // this shard is empty: the next one, until all eight have been seen empty
+                    if (c >= (zone ? n_chunks : n_main)) { // this shard is empty: the next one, until all eight have been seen empty
                         if (++shards_seen_empty == 8) {
+                            if (zone == 0u && late_wave && n_main < n_chunks) { // on to the chunks kept for the old waves
+                                zone              = 1u;
+                                shards_seen_empty = 0;
+                                continue;
+                            }
                             more = false;
+                            if (P.express_tail == 2u)
+                                __builtin_amdgcn_s_setprio(3);
 #ifdef RT_WAVETIMES
                             wt_dry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -718,6 +825,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 any_bits  = 0;
                 sub       = 0;
                 st        = ST_CELL;
+                born      = wave_iter;
             }
         }
         // (at this point every lane is idle, waits for [A], or is in [B] / [C]: the three lane masks the loop
@@ -743,13 +851,21 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         // for P.park <= 12 the threshold is P.park itself, and the adaptive form runs only in the tail of the launch)
         const unsigned long long want_a = __ballot(st == ST_CELL);
         int park_at = (int) P.park;
-        if (!more || (int) P.park > 12 || REFILL > 8) {
+        if (!more || old_wave || (int) P.park > 12 || REFILL > 8) {
             const int n_live = WAVE - (int) __popcll(idle2);
             const int fifth  = (n_live * 13 + 63) >> 6; // ~ n_live / 5, at least 1 for a live lane
             park_at          = fifth < (int) P.park ? fifth : (int) P.park;
+            // an express wave holds long rays only: most of their iterations are integrator steps inside one cell, so
+            // [A] is worth deferring much longer than in a wave of average rays (P.express_park 64ths of the live lanes)
+            if (old_wave && P.express_park != 0u)
+                park_at = (n_live * (int) P.express_park + 63) >> 6;
         }
         const bool do_a = (int) __popcll(want_a) >= park_at || (~(idle2 | want_a)) == 0ull;
         bool last_of_tile = false; // FUSED: the lane's ray ends in this iteration and was the last one of its tile
+#ifdef RT_WAVETIMES
+        wt_a_runs += (do_a && want_a != 0ull) ? 1u : 0u;
+        wt_b_runs += __ballot(st == ST_XSETUP) != 0ull ? 1u : 0u; // (lanes that arrive from [A2] in this iteration not counted)
+#endif
         if (do_a && st == ST_CELL) {
             bool in_seg        = !escaped & (z < 0.995f * z_stop);
             if (!in_seg) {
@@ -940,12 +1056,31 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         if (FUSED) {
             unsigned long long lm = __ballot(last_of_tile);
             if (lm != 0ull) {
+#ifdef RT_WAVETIMES
+                const unsigned long long vm0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's record stores have landed
+#ifdef RT_WAVETIMES
+                if (lane == 0)
+                    g_wt_vm[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u] += __builtin_amdgcn_s_memrealtime() - vm0;
+#endif
                 do {
                     const int l0 = (int) __ffsll((long long) lm) - 1;
                     lm &= lm - 1ull;
+#ifdef RT_WAVETIMES
+                    const unsigned long long pub0 = __builtin_amdgcn_s_memrealtime();
+#endif
                     if (lane == l0)
                         tile_publish(done, ridx >> 6);
+#ifdef RT_WAVETIMES
+                    if (lane == l0) {
+                        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - pub0;
+                        unsigned long long *q = g_wt_pub[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u];
+                        q[0] += dt;
+                        q[1] += 1;
+                        q[3] = dt > q[3] ? dt : q[3];
+                    }
+#endif
                     slot_busy &= ~(1u << (unsigned) __builtin_amdgcn_readlane((int) cslot, l0));
                 } while (lm != 0ull);
             }
@@ -1091,6 +1226,8 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         }
         } // some lane is marching
     }
+    if (P.express_age != 0u || P.express_tail != 0u)
+        __builtin_amdgcn_s_setprio(0);
 
 #ifdef RT_WAVETIMES
     if (lane == 0) {
@@ -1140,7 +1277,8 @@ template <bool LDS_TAB, bool BOUNDED>
 __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    march_wave<LDS_TAB, BOUNDED, false>(P, lds_raw, TileList{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u });
+    march_load_tables<LDS_TAB>(P, lds_raw);
+    march_wave<LDS_TAB, BOUNDED, false>(P, lds_raw, TileList{ nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, 0u });
 }
 
 } // namespace rt

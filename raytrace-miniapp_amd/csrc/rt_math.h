@@ -30,7 +30,7 @@ struct Inst {
 #endif
 // Second diagnostic build (-DRT_TIMEBLOCKS): wave clock spent in each block of the march
 // loop, g_inst[i] = cycles between mark i and mark i+1 summed over waves, g_inst[7] = iterations.
-#ifdef RT_TIMEBLOCKS
+#if defined(RT_TIMEBLOCKS) || defined(RT_WAVEBLOCKS)
 #ifndef RT_INSTRUMENT
 __device__ unsigned long long g_inst[8];
 #endif
