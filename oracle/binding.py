@@ -151,6 +151,64 @@ class Reference:
                                              cabi.c_float_p, cabi.c_float_p]
         L.ref_calc_ray_path_file.restype = C.c_int
 
+    def scale_file(self, path, scale: float) -> dict:
+        """The reference's scale_problem (src/CreateImageHelpers.cpp:104-150) applied to a .dat file: the grids it leaves
+        in euv_beam and (if present) seed_beam."""
+        L = self.lib
+        L.ref_scale_file.argtypes = [C.c_char_p, C.c_double, C.c_int, P(C.c_int), cabi.c_double_p, cabi.c_double_p]
+        L.ref_scale_file.restype = C.c_int
+        out = {}
+        for which, key in ((0, "beam"), (1, "seed_beam")):
+            dims = (C.c_int * 4)()
+            d = np.zeros(4)
+            rc = L.ref_scale_file(str(path).encode(), scale, which, dims, cabi._dp(d), None)
+            if rc < 0:
+                raise FileNotFoundError(path)
+            if rc == 1:
+                continue
+            n = list(dims)
+            g = np.zeros(sum(n))
+            L.ref_scale_file(str(path).encode(), scale, which, dims, cabi._dp(d), cabi._dp(g))
+            o = np.cumsum([0] + n)
+            out[key] = dict(n=np.array(n), d=d.copy(), x=g[o[0]:o[1]].copy(), y=g[o[1]:o[2]].copy(), a=g[o[2]:o[3]].copy(),
+                            b=g[o[3]:o[4]].copy())
+        return out
+
+    def cpu_loop_sliced(self, problem, rays=None, max_nv: int = 96):
+        """RayTraceImageCPULoop on a problem with more frequencies than the reference's K_MAX = 100
+        (src/common/RayTraceImageHelper.h:30, src/RayTraceImage.cpp:231) allows: the frequencies are independent given
+        a ray's march (SURVEY.md 8(c) iii), so the frequency axis is cut into slices of at most max_nv, each slice is a
+        problem of its own for the reference, the images are concatenated along k and I_ang is the sum over the slices
+        (returned per slice as well)."""
+        import copy
+        rt = importlib.import_module("raytrace-miniapp_amd")
+        b = problem.beam
+        K = b.nv
+        if rays is None:
+            rays = problem.build_rays()
+        image = np.zeros((b.nx * b.ny, K))
+        parts, code, secs = [], 0, 0.0
+        for k0 in range(0, K, max_nv):
+            k1 = min(K, k0 + max_nv)
+            q = copy.copy(problem)
+            qb = copy.copy(b)
+            qb.dv = np.ascontiguousarray(b.dv[k0:k1])
+            if getattr(b, "v", None) is not None and len(b.v) == K:
+                qb.v = np.ascontiguousarray(b.v[k0:k1])
+            q.beam = qb
+            q.gain = [rt.Gain(g.x, g.y, g.n, g.g0, g.E0, np.ascontiguousarray(g.gv.reshape(-1, K)[:, k0:k1]).reshape(-1), k1 - k0)
+                      for g in problem.gain]
+            if problem.seed is not None:
+                sd = problem.seed
+                q.seed = rt.Seed(sd.x[:4] + [np.ascontiguousarray(sd.x[4][k0:k1])], sd.f[:4] + [np.ascontiguousarray(sd.f[4][k0:k1])], sd.f0)
+            r = self.cpu_loop(q, rays)
+            image[:, k0:k1] = r["image"].reshape(-1, k1 - k0)
+            parts.append(r["I_ang"])
+            code |= r["failure_code"]
+            secs += r["seconds"]
+        return dict(image=image.reshape(-1), I_ang=np.sum(parts, axis=0), I_ang_slices=np.array(parts), failure_code=code,
+                    seconds=secs, slices=[(k0, min(K, k0 + max_nv)) for k0 in range(0, K, max_nv)])
+
     def cpu_loop(self, problem, rays=None):
         m = cabi.Marshalled(problem)
         if rays is None:

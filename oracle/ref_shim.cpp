@@ -13,6 +13,7 @@
  *   RayTraceImageCPULoop      (src/RayTraceImageCPU.cpp:19)
  *   RayTrace::create_image    (src/RayTraceImage.cpp:227)
  *   create_image_struct::unpack (src/RayTraceStructures.cpp:2224)
+ *   scale_problem             (src/CreateImageHelpers.cpp:144)
  */
 #include "RayTrace.h"
 #include "common/RayTraceImageHelper.h"
@@ -29,6 +30,8 @@ extern void RayTraceImageCPULoop(int N, const RayTrace::EUV_beam_struct &euv_bea
     const RayTrace::ray_gain_struct *gain, const RayTrace::ray_seed_struct *seed, int method,
     const std::vector<ray_struct> &rays, double scale, double *image, double *I_ang,
     unsigned int &failure_code, std::vector<ray_struct> &failed_rays);
+
+void scale_problem(RayTrace::create_image_struct &info, double scale); // src/CreateImageHelpers.h:18
 
 namespace {
 
@@ -244,6 +247,45 @@ int ref_calc_rays_file(const char *path, size_t stride, size_t n, double *Iv_out
     }
     free_info(info);
     return 0;
+}
+
+/* The reference's own enlargement rule, scale_problem (src/CreateImageHelpers.cpp:104-150), applied to a loaded file:
+ * the grids it leaves in euv_beam (which = 0) or seed_beam (which = 1).  dims[0..3] = nx, ny, na, nb; d[0..3] = dx, dy,
+ * da, db; grids (may be NULL: sizes only) receives x | y | a | b back to back.  Returns 1 if the file has no such beam. */
+int ref_scale_file(const char *path, double scale, int which, int *dims, double *d, double *grids)
+{
+    RayTrace::create_image_struct *info = load_file(path);
+    if (!info)
+        return -1;
+    scale_problem(*info, scale);
+    int rc = 0;
+    if (which == 0) {
+        const RayTrace::EUV_beam_struct *b = info->euv_beam;
+        dims[0] = b->nx; dims[1] = b->ny; dims[2] = b->na; dims[3] = b->nb;
+        d[0] = b->dx; d[1] = b->dy; d[2] = b->da; d[3] = b->db;
+        if (grids) {
+            double *q = grids;
+            memcpy(q, b->x, sizeof(double) * b->nx); q += b->nx;
+            memcpy(q, b->y, sizeof(double) * b->ny); q += b->ny;
+            memcpy(q, b->a, sizeof(double) * b->na); q += b->na;
+            memcpy(q, b->b, sizeof(double) * b->nb);
+        }
+    } else if (info->seed_beam) {
+        const RayTrace::seed_beam_struct *b = info->seed_beam;
+        dims[0] = b->nx; dims[1] = b->ny; dims[2] = b->na; dims[3] = b->nb;
+        d[0] = b->dx; d[1] = b->dy; d[2] = b->da; d[3] = b->db;
+        if (grids) {
+            double *q = grids;
+            memcpy(q, b->x, sizeof(double) * b->nx); q += b->nx;
+            memcpy(q, b->y, sizeof(double) * b->ny); q += b->ny;
+            memcpy(q, b->a, sizeof(double) * b->na); q += b->na;
+            memcpy(q, b->b, sizeof(double) * b->nb);
+        }
+    } else {
+        rc = 1;
+    }
+    free_info(info);
+    return rc;
 }
 
 /* RayTrace::calc_ray_path (src/RayTraceImage.cpp:440-477) on a sub-grid of the file's own

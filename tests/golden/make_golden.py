@@ -67,5 +67,46 @@ def main():
               f"ref cpu {r['seconds']:.2f}s, {n} probe rays")
 
 
+def main_scaled_and_sliced():
+    """Fixtures that pin the full-size configurations to the reference itself:
+      scale16_ref_grids.npz    the grids the reference's own scale_problem(info, 16) leaves (src/CreateImageHelpers.cpp:104-150)
+                               for both shipped files -- what BASELINE config 3 (the ASE_medium / seed_medium stand-in) is
+                               built from;
+      config5_tile_ref.npz     the centre 64 x 64-pixel tile of BASELINE config 5 (4096 x 4096 pixels, nv = 512) through the
+                               reference's RayTraceImageCPULoop as six frequency slices of <= 96 (the reference stops at
+                               nv < K_MAX = 100, RayTraceImageHelper.h:30): every 4th pixel's full row, every
+                               pixel's sum over k, I_ang per slice."""
+    build(ref=True)
+    ref = Reference()
+    grids = {}
+    for name in ("ASE_small", "seed_small"):
+        r = ref.scale_file(REF / f"{name}.dat", 16.0)
+        for beam, g in r.items():
+            for key, val in g.items():
+                grids[f"{name}.{beam}.{key}"] = val
+    np.savez_compressed(OUT / "scale16_ref_grids.npz", **grids)
+    problem_mod = importlib.import_module("raytrace-miniapp_amd.problem")
+    base = rt.datfile.load(REF / "ASE_small.dat")
+    n, T, K = 4096, 64, 512
+    p = problem_mod.regrid_beam(problem_mod.resample_frequency(base, K), nx=n, ny=n, a_centre=-1.0, b_centre=-4.5)
+    i0 = j0 = n // 2 - T // 2
+    import copy
+    q = copy.copy(p)
+    b = copy.copy(p.beam)
+    b.x = np.ascontiguousarray(p.beam.x[i0:i0 + T])
+    b.y = np.ascontiguousarray(p.beam.y[j0:j0 + T])
+    q.beam = b
+    r = ref.cpu_loop_sliced(q, max_nv=96)
+    assert r["failure_code"] == 0
+    img = r["image"].reshape(T, T, K)                       # [iy][ix][k]
+    np.savez_compressed(OUT / "config5_tile_ref.npz", n=n, T=T, K=K, i0=i0, j0=j0, rows=img[::4, ::4, :].copy(),
+                        row_sums=img.sum(axis=2), I_ang=r["I_ang"], I_ang_slices=r["I_ang_slices"],
+                        slices=np.array(r["slices"]))
+    print(f"config 5 centre tile: |image|={np.linalg.norm(r['image']):.12g}, I_ang={r['I_ang'][0]:.12g}, "
+          f"reference {r['seconds']:.1f} s in {len(r['slices'])} slices")
+
+
 if __name__ == "__main__":
-    main()
+    if "--scaled" not in sys.argv:
+        main()
+    main_scaled_and_sliced()

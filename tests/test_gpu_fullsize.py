@@ -126,6 +126,23 @@ def test_config5_full_size_tiles_vs_oracle(hip, oracle, ase_small):
     del image, img
 
 
+def test_config5_centre_tile_vs_reference_frequency_slices(hip, ase_small):
+    """The centre 64 x 64 tile of config 5 against the REFERENCE ITSELF: RayTraceImageCPULoop cannot take nv = 512 in one
+    piece (K_MAX = 100, src/common/RayTraceImageHelper.h:30), so the fixture holds its answer from six frequency slices of
+    <= 96 (tests/golden/make_golden.py): every 4th pixel's row, every pixel's sum over k, I_ang."""
+    from test_oracle_pin import config5_centre_tile
+    q, fx = config5_centre_tile(ase_small)
+    T, K = int(fx["T"]), int(fx["K"])
+    with hip.Plan(q) as plan:
+        out = plan.set_ray_grid().run().fetch()
+    assert out["failure_code"] == 0
+    img = out["image"].reshape(T, T, K)
+    assert rel_l2(img[::4, ::4, :], fx["rows"]) < TOL
+    assert rel_l2(img.sum(axis=2), fx["row_sums"]) < TOL
+    assert rel_l2(out["I_ang"], fx["I_ang"]) < TOL
+    assert np.linalg.norm(fx["rows"]) > 0
+
+
 def copy_beam_window(p, i0, j0, T):
     """The sub-problem whose deposit / ray grid is the T x T pixel window at (i0, j0) of p's beam."""
     import copy

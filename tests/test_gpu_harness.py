@@ -58,6 +58,27 @@ def test_reference_harness_with_hip_backend(tmp_path, name):
         assert r.stdout.count("two-sided rel-L2 vs cpu") == 2
 
 
+def test_config3_through_the_references_own_scale_problem_and_cpu_loop(tmp_path):
+    """BASELINE config 3 against the reference itself: `-scale=16` makes the harness apply the reference's own
+    scale_problem (src/CreateImageHelpers.cpp:104-150) to ASE_small.dat -- 6,384,000 rays, the ASE_medium stand-in -- and
+    run its own RayTraceImageCPULoop beside the HIP loop; the two-sided rel-L2 it prints must be within 1e-5 for image
+    and I_ang.  (check_ans does not run at scale != 1, src/CreateImage.cpp:156: the file's golden arrays are for scale 1.)"""
+    import re
+    need(BIN)
+    dat = tmp_path / "ASE_small.dat"
+    dat.write_bytes(lzma.decompress((ROOT / "tests" / "golden" / "ASE_small.dat.xz").read_bytes()))
+    r = subprocess.run([str(BIN), "-methods=cpu,Hip", "-iterations=1", "-scale=16", str(dat)],
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout, r.stderr)
+    assert "correctness errors: 0," in r.stdout, r.stdout + r.stderr
+    m = re.search(r"two-sided rel-L2 vs cpu: image (\S+)\s+I_ang (\S+)", r.stdout)
+    assert m, r.stdout
+    assert float(m.group(1)) <= 1e-5 and float(m.group(2)) <= 1e-5
+    row = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("Hip ")][0].split()
+    # ray-steps/s over rays/s = cell steps per ray of the 6,384,000-ray stand-in (75,601,675 ray-steps: SURVEY.md 8(d))
+    assert abs(float(row[6]) / float(row[5]) - 75601675 / 6384000) < 1e-2
+
+
 def _write_dat(path, name, mutate=None):
     import importlib
     rt = importlib.import_module("raytrace-miniapp_amd")
