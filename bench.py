@@ -83,6 +83,40 @@ def algorithmic_bytes(n_rays: int, cell_steps: int, L: int, K: int, seeded: bool
     return {"march": march, "freq": freq, "path": march + freq, "write": 8 * (n_pix * K + n_ang)}
 
 
+def bounded_roof(alg_bytes: float, seconds: float, traffic: float | None = None, sq: dict | None = None,
+                 clock_hz: float = 2.4e9, prefix: str = "") -> dict:
+    """Roofline fields of a sub-record that can never show a fraction above 1.  `contract_frac` is the yardstick of
+    SURVEY.md 8(d) -- ALGORITHMIC bytes of the contract formula over the time against the HBM peak -- which prices
+    lineshape rows and grid nodes that the caches serve and therefore exceeds 1 on several workloads: it is a figure of
+    merit, not a bound.  `frac` is a bound that can bind: HBM bytes measured by the counter passes over the time against the
+    peak (null while no counter pass of these kernel sources is committed), and `issue_frac` the VALU + SALU
+    wave-instructions per second against one per two cycles per SIMD, from the SQ pass of the same workload."""
+    contract = alg_bytes / seconds / 1e9
+    d = {prefix + "contract_achieved": contract, prefix + "contract_frac": contract / HBM_PEAK_GBS,
+         prefix + "bound": "hbm", prefix + "peak": HBM_PEAK_GBS, prefix + "unit": "GB/s"}
+    if traffic:
+        d[prefix + "achieved"] = traffic / seconds / 1e9
+        d[prefix + "frac"] = traffic / seconds / 1e9 / HBM_PEAK_GBS
+        d[prefix + "achieved_basis"] = "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes) over this run's time"
+    elif contract / HBM_PEAK_GBS <= 1.0:
+        d[prefix + "achieved"] = contract
+        d[prefix + "frac"] = contract / HBM_PEAK_GBS
+        d[prefix + "achieved_basis"] = "algorithmic bytes of the contract formula (no counter pass of these kernel sources)"
+    else:
+        d[prefix + "achieved"] = None
+        d[prefix + "frac"] = None
+        d[prefix + "achieved_basis"] = ("no counter pass of these kernel sources is committed, and the contract formula "
+                                        "exceeds what HBM can deliver (cache-served rows): see contract_frac")
+    c = (sq or {}).get("avg", {}) if sq else {}
+    if c.get("SQ_INSTS_VALU"):
+        instr = c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_SALU", 0.0)
+        peak = N_SIMD * clock_hz / 2.0
+        d[prefix + "issue_frac"] = instr / seconds / peak
+        d[prefix + "issue"] = {"bound": "valu+salu issue", "achieved": instr / seconds / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+                               "valu_instr_per_launch": c["SQ_INSTS_VALU"], "salu_instr_per_launch": c.get("SQ_INSTS_SALU")}
+    return d
+
+
 def kernel_source_hash() -> str:
     """sha1 over the kernel sources (the device code: KERNEL_SOURCES below, not the host translation units):
     profiles/summarize.py stamps the committed counter summary with it, and the counters are quoted only while the
@@ -101,7 +135,7 @@ def committed_counters() -> dict:
     """Counter passes are separate rocprofv3 runs (MI355X_MICROARCH.md); their summary is committed
     under profiles/ and quoted here with its source, the commit it was taken at and the hash of the kernel
     sources it was taken on.  Counters of other kernel sources are NOT quoted: {"_stale": ...}."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             try:
@@ -350,16 +384,20 @@ def measure_config5(torch, backend, rt, problem_mod, dev, counters: dict) -> dic
     rec = {"workload": "synthetic 4096x4096x512, na = nb = 1", "rays": st["n_rays"], "ray_steps": st["cell_steps"],
            "march_ms": march, "freq_ms": freq, "kernel_ms": march + freq, "kernel_ms_min": min(m + f for m, f in ms), "runs": len(ms),
            "algorithmic_read_bytes": alg["path"], "algorithmic_write_bytes": alg["write"],
-           "bound": "hbm", "achieved": alg["path"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg["path"] / t / 1e9 / HBM_PEAK_GBS,
            "read_plus_write_GBs": (alg["path"] + alg["write"]) / t / 1e9, "store_GBs": alg["write"] / t / 1e9,
+           "store_floor_ms": alg["write"] / (HBM_PEAK_GBS * 1e9) * 1e3,
            "ray_steps_per_sec": st["cell_steps"] / t,
            "iang_identity_rel_err": abs(lhs - rhs) / abs(rhs) if rhs else None,
            "limiter": f"{st['n_rays'] * 6 * b.nv / 1e9:.1f} G float64 exponential updates (f64 VALU issue) beside "
                       f"{alg['write'] / 1e9:.1f} GB of stores; not HBM reads"}
     c5 = counters.get("config5", {})
     rec["traffic"] = c5.get("hbm_bytes_per_step")
-    rec["traffic_source"] = (counters.get("_source") + " (config5 counter pass)") if c5 else None
+    rec["traffic_source"] = (counters.get("_source") + " (config5 counter pass)") if c5 else counters.get("_stale")
+    fk = c5.get("pmc_sq", {}).get("rt_freq_kernel")
+    rec.update(bounded_roof(alg["path"], t, rec["traffic"], None, counters.get("shader_clock_hz", 2.4e9)))
+    if fk:
+        rec["freq_kernel_issue"] = bounded_roof(alg["freq"], freq * 1e-3, None, fk, counters.get("shader_clock_hz", 2.4e9)).get("issue")
+        rec["freq_kernel_issue_frac"] = bounded_roof(alg["freq"], freq * 1e-3, None, fk, counters.get("shader_clock_hz", 2.4e9)).get("issue_frac")
     return rec
 
 
@@ -461,19 +499,21 @@ def measure_seed_medium(torch, backend, rt, dev, counters: dict) -> dict:
            "kernel_ms": march + freq, "kernel_ms_min": min(m + f for m, f in ms), "runs": len(ms),
            "ray_steps_per_sec": st["cell_steps"] / t,
            "algorithmic_bytes": alg["path"], "bytes_per_ray_step": alg["path"] / max(1, st["cell_steps"]),
-           "bound": "hbm", "achieved": alg["path"] / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg["path"] / t / 1e9 / HBM_PEAK_GBS,
-           "dominant_kernel": {"kernel": "rt_march_kernel", "kernel_ms_avg": march, "algorithmic_bytes_per_launch": alg["march"],
-                               "achieved": alg["march"] / (march * 1e-3) / 1e9, "frac": alg["march"] / (march * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "freq_kernel": {"kernel": "rt_freq_kernel", "kernel_ms_avg": freq, "algorithmic_bytes_per_launch": alg["freq"],
-                           "achieved": alg["freq"] / (freq * 1e-3) / 1e9, "frac": alg["freq"] / (freq * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "the contract's (256 + 8 K) R_live term prices a per-ray seed evaluation; the kernel reads "
-                                   "tabulated per-axis seed factors instead, so this split can exceed 1 -- the path figure is "
-                                   "the meaningful one"},
            "failure_code": st.get("failure_code")}
     sm = counters.get("seed_medium", {})
     rec["traffic"] = sm.get("hbm_bytes_per_step")
     rec["traffic_source"] = (counters.get("_source") + " (seed_medium counter pass)") if sm else counters.get("_stale")
+    clk = counters.get("shader_clock_hz", 2.4e9)
+    ker, sq = sm.get("kernels", {}), sm.get("pmc_sq", {})
+    rec.update(bounded_roof(alg["path"], t, rec["traffic"], None, clk))
+    rec["dominant_kernel"] = {"kernel": "rt_march_kernel", "kernel_ms_avg": march, "algorithmic_bytes_per_launch": alg["march"],
+                              **bounded_roof(alg["march"], march * 1e-3, ker.get("rt_march_kernel", {}).get("hbm_bytes_per_launch"),
+                                             sq.get("rt_march_kernel"), clk)}
+    rec["freq_kernel"] = {"kernel": "rt_freq_kernel", "kernel_ms_avg": freq, "algorithmic_bytes_per_launch": alg["freq"],
+                          **bounded_roof(alg["freq"], freq * 1e-3, ker.get("rt_freq_kernel", {}).get("hbm_bytes_per_launch"),
+                                         sq.get("rt_freq_kernel"), clk),
+                          "note": "the contract's (256 + 8 K) R_live term prices a per-ray seed evaluation; the kernel reads "
+                                  "tabulated per-axis seed factors instead, so contract_frac of this split exceeds 1"}
     return rec
 
 
@@ -518,9 +558,8 @@ def measure_small_files(torch, backend, rt, dev) -> dict:
         rec = {"file": f"{name}.dat (reference input, unchanged)", "rays": st["n_rays"], "ray_steps": st["cell_steps"], "nv": b.nv,
                "march_ms": march, "freq_ms": freq, "kernel_ms_avg": march + freq, "runs": len(ms),
                "ray_steps_per_sec": st["cell_steps"] / t,
-               "algorithmic_bytes": alg["path"], "bound": "hbm", "achieved": alg["path"] / t / 1e9, "peak": HBM_PEAK_GBS,
-               "unit": "GB/s", "frac": alg["path"] / t / 1e9 / HBM_PEAK_GBS,
-               "march_frac": alg["march"] / (march * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "algorithmic_bytes": alg["path"], **bounded_roof(alg["path"], t),
+               "march_contract_frac": alg["march"] / (march * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "ms_per_image": min(wall), "ms_per_image_mean": sum(wall) / len(wall), "python_wall_ms_min": min(pywall),
                "image_loop_ray_steps_per_sec": res["stats"]["cell_steps"] / (min(wall) * 1e-3),
                "failure_code": res["failure_code"]}
@@ -616,8 +655,9 @@ def main() -> int:
     ap.add_argument("--no-small", action="store_true", help="skip the ASE_small / seed_small sub-record of the default N = 1 run")
     ap.add_argument("--no-cabi-multi", action="store_true", help="skip the rt_hip_multi_image_loop sub-record (a child process)")
     ap.add_argument("--clock-ramp-steps", type=int, default=None,
-                    help="further untimed steps after --warmup, before the timed region (reported in `warmup`): 64, or 0 "
-                         "with --no-extras, unless given")
+                    help="further untimed steps after --warmup, before the timed region (reported in `warmup`); default 0: "
+                         "the driver's --warmup is the protocol (round 4 ran 64 by default; the steady_state loop beside "
+                         "the timed region shows the steady clock)")
     ap.add_argument("--cabi-multi-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-assemble", action="store_true",
                     help="N > 1: leave the tiles on their GPUs (config 5: gathering the 68.7 GB image takes longer than "
@@ -684,10 +724,11 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     # The W warm-up steps of a 3 ms step last ~10 ms: the shader clock is still ramping when the timed region
-    # starts (the first timed steps run 5-15 % longer than the steady state).  --clock-ramp-steps further UNTIMED
-    # steps (default 64, the same on every rank) let the K timed steps see the clock a production loop sees; the
-    # line's `warmup` is the total number of untimed steps that ran, `warmup_requested` the --warmup part of it.
-    extra_warm = max(0, args.clock_ramp_steps) if args.clock_ramp_steps is not None else (0 if args.no_extras else 64)
+    # starts (the first timed steps can run a few per cent longer than the steady state).  --clock-ramp-steps further
+    # UNTIMED steps (default 0 since round 5: the driver's --warmup is the protocol; `steady_state` below is the long loop)
+    # may be asked for; the line's `warmup` is the total number of untimed steps that ran, `warmup_requested` the
+    # --warmup part of it.
+    extra_warm = max(0, args.clock_ramp_steps) if args.clock_ramp_steps is not None else 0
     for _ in range(extra_warm):
         step()
     torch.cuda.synchronize()
@@ -794,8 +835,11 @@ def main() -> int:
             # rate, from the same passes) are given beside it, each labelled.
             ach = alg[name] / (ms * 1e-3) / 1e9
             traffic = hbm.get(kname, {}).get("hbm_bytes_per_launch")
-            r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                 "achieved_basis": "algorithmic bytes of the contract formula (16 R + C_step S | 4 K 3 L R), not HBM traffic",
+            cf = ach / HBM_PEAK_GBS
+            r = {"bound": "hbm", "achieved": ach if cf <= 1.0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": cf if cf <= 1.0 else None, "contract_achieved": ach, "contract_frac": cf,
+                 "achieved_basis": "algorithmic bytes of the contract formula (16 R + C_step S | 4 K 3 L R), not HBM traffic"
+                                   + ("" if cf <= 1.0 else "; above 1 (cache-served rows): quoted as contract_frac only, frac is null"),
                  "traffic": traffic,
                  "traffic_source": (counters["_source"] + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                     "command, gfx950 corrections applied; not measured in this run") if kname in hbm
@@ -813,7 +857,7 @@ def main() -> int:
                 rate = instr / (ms * 1e-3)
                 peak = N_SIMD * clock / 2.0
                 r["binding"] = {"bound": "valu+salu issue", "achieved": rate / 1e9, "peak": peak / 1e9,
-                                "unit": "G wave-instr/s", "frac": rate / peak,
+                                "unit": "G wave-instr/s", "frac": min(rate / peak, 1.0), "raw_frac": rate / peak,
                                 "valu_instr_per_launch": c["SQ_INSTS_VALU"], "salu_instr_per_launch": c.get("SQ_INSTS_SALU"),
                                 "source": counters["_source"] + " (committed SQ counter pass, instruction counts per launch)"}
                 r["secondary"] = r["binding"]
@@ -845,8 +889,7 @@ def main() -> int:
             # whole are listed next to it
             "roofline": dominant,
             "roofline_kernels": kernels,
-            "roofline_path": {"bound": "hbm", "achieved": path_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": path_ach / HBM_PEAK_GBS, "kernel_ms_sum": kernel_ms,
+            "roofline_path": {**bounded_roof(alg["path"], kernel_ms * 1e-3), "kernel_ms_sum": kernel_ms,
                               "algorithmic_bytes": alg["path"],
                               "bytes_per_ray_step": alg["path"] / max(1, stats["cell_steps"])},
         }
@@ -869,10 +912,12 @@ def main() -> int:
                     "what": "the same step as two launches (RT_HIP_FUSED=2): march kernel, records in HBM / L2, frequency kernel",
                     "runs": len(tk), "kernel_ms_sum": m2 + f2, "one_launch_speedup": (m2 + f2) / kernel_ms,
                     "march": {"kernel": "rt_march_kernel", "kernel_ms_avg": m2, "algorithmic_bytes_per_launch": alg["march"],
-                              "frac": alg["march"] / (m2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                              **bounded_roof(alg["march"], m2 * 1e-3, None, counters.get("two_kernel", {}).get("pmc_sq", {}).get("rt_march_kernel"),
+                                             counters.get("shader_clock_hz", 2.4e9))},
                     "freq": {"kernel": "rt_freq_kernel", "kernel_ms_avg": f2, "algorithmic_bytes_per_launch": alg["freq"],
-                             "frac": alg["freq"] / (f2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                    "path_frac": alg["path"] / ((m2 + f2) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             **bounded_roof(alg["freq"], f2 * 1e-3, None, counters.get("two_kernel", {}).get("pmc_sq", {}).get("rt_freq_kernel"),
+                                            counters.get("shader_clock_hz", 2.4e9))},
+                    "path_contract_frac": alg["path"] / ((m2 + f2) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception as exc:  # noqa: BLE001
                 line["roofline_two_kernel"] = {"error": repr(exc)}
             finally:

@@ -117,6 +117,9 @@ def workload_traffic(root, here, tag, prefix, name):
         tot += rd + wr
     if rec["kernels"]:
         rec["hbm_bytes_per_step"] = tot
+    sq = pmc(root, f"{prefix}_sq")  # instruction counts per launch: what share of the issue rate the workload's kernels use
+    if sq:
+        rec["pmc_sq"] = sq
     return rec
 
 
