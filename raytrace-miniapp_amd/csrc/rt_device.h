@@ -216,7 +216,7 @@ struct DevParams {
     unsigned int express_age, express_hold, express_park, express_tail;
     // the last late_chunks chunks of a march launch are handed out to the first late_waves waves of each work-group only
     // (rt_march.hip, "The end of a launch"); 0: no such zone
-    unsigned int late_chunks, late_waves;
+    unsigned int late_chunks, late_waves, late_first; // late_first: the first of those waves (the first MARCHING wave of a work-group)
     unsigned char *bad; // [n_rays], only in the repeat
 };
 

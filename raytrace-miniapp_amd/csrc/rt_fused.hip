@@ -60,7 +60,11 @@ struct FusedKArg {
 // then 3.1 KB instead of 3.6 and fifteen of sixteen fit beside the tables of the shipped grids, so that only the last
 // wave of a work-group to leave the march -- which waits for nobody -- takes an overlaid one)
 constexpr int fused_wave_doubles(int maxq) { return 4 * XP_ROW + maxq * WAVE; }
-template <bool BOUNDED, int SF, int MAXQ>
+// EMIS = false: the gain-only (seeded) frequency pass.  Its tiles span half a dozen pixels, so a wave that runs it needs a
+// row cache behind its transposition rows (lay.per_wave says how much, H.nslot how many rows): only a handful of such
+// buffers fit beside the march tables -- they go to the consumers, which run the frequency pass during the march; a wave
+// that leaves the march takes a buffer over the tables once the last marcher is done.
+template <bool BOUNDED, int SF, int MAXQ, bool EMIS = true>
 __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     return;
 #endif
     double *xpose = mine;
-    double *cache = mine + fused_wave_doubles(MAXQ); // (no row cache in this kernel: nslot = 0)
+    double *cache = mine + fused_wave_doubles(MAXQ); // (row cache of the gain-only instance; the emission instance has none: nslot = 0)
 #ifdef RT_WAVETIMES
     const unsigned long long fu_buf = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         const int k0 = (tile & TILE_PART_FLAG) ? (int) (part * A.lay.k_part) : 0;
         const int k1 = (tile & TILE_PART_FLAG) && part < 3u ? k0 + (int) A.lay.k_part : 0x7fffffff;
         if (k0 < H.K)
-            freq_tile<SF, true, MAXQ>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile & TILE_ID_MASK, lane_t, k0, k1);
+            freq_tile<SF, EMIS, MAXQ>(H, hflags, C, lds_iang, exp2_tab, xpose, cache, tile & TILE_ID_MASK, lane_t, k0, k1);
 #ifdef RT_WAVETIMES
         if (!fu_first)
             fu_first = __builtin_amdgcn_s_memrealtime();

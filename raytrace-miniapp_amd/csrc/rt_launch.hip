@@ -266,8 +266,11 @@ int plan_repeat_checked(rt_hip_plan *p)
 // The chunks at the end of the ray list that only the oldest wave of every SIMD takes (rt_march.hip, "The end of a
 // launch"): about as many rays as those waves march in one drain period, RT_HIP_LATE_X10 tenths of a ray per lane of
 // theirs (0: no such zone), at most a quarter of the launch.
-static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg)
+static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg, unsigned first_marching_wave)
 {
+    // (the waves that take the late chunks must be waves that march: waves_per_wg counts the marching waves,
+    // first_marching_wave is where they start inside the work-group)
+    p->P.late_first = first_marching_wave;
     const unsigned x10   = env_unsigned("RT_HIP_LATE_X10", 32, 0, 1000);
     const unsigned waves = env_unsigned("RT_HIP_LATE_WAVES", 4, 0, 16);
     p->P.late_waves  = waves < waves_per_wg ? waves : waves_per_wg;
@@ -312,8 +315,16 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     // with at least 32 rays per pixel (a 64-ray tile then spans at most three pixels: the few-runs deposit, which
     // needs no row cache), tables in LDS, nothing that wants the march records to itself (probe, path tracer,
     // the checking repeat, profiling switches), and room in LDS for the frequency pass beside the tables
-    const bool fused_cand = lds_tab && n_launch == 1 && p->n_rays > 0 && !p->path_on && !p->probe_on && p->P.debug == 0 && p->P.use_emis &&
-                            !p->P.exclusive && p->P.safe == 0 && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32 &&
+    // (The gain-only mode -- a seed, forward method -- on a ray grid can run as one launch as well: its frequency pass needs a
+    // row cache per wave, so only the handful of waves whose buffers fit beside the march tables run it during the march
+    // (the layout below).  Built and measured in round 5, profiles/r05_seed_fused_ab.txt: seed_small.dat 3.28 against
+    // 3.33 ms with four such waves, twice the rays 5.97 against 5.93 ms -- a wash, because what the one launch buys is the
+    // idle end of the march, which is a fifth of a 0.5 ms launch and a hundredth of a 6 ms one, and what it costs is five
+    // of sixteen waves marching less.  Two kernels stay the rule for this mode; RT_HIP_FUSED_SEED=1 takes the one launch.)
+    const bool fused_emis = p->P.use_emis && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32;
+    const bool fused_gain = !p->P.use_emis && p->P.rays.list == nullptr && env_unsigned("RT_HIP_FUSED_SEED", 0, 0, 1) == 1;
+    const bool fused_cand = lds_tab && n_launch == 1 && p->n_rays > 0 && !p->path_on && !p->probe_on && p->P.debug == 0 &&
+                            (fused_emis || fused_gain) && !p->P.exclusive && p->P.safe == 0 &&
                             p->n_iang * sizeof(double) <= 32 * 1024 && env_unsigned("RT_HIP_FUSED", 1, 1, 2) == 1;
     unsigned bthr = lds_tab ? 1024u : 256u;
     if (lds_tab && !fused_cand) {
@@ -393,12 +404,16 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     p->last_fused = false;
     p->P.late_chunks = 0;
     p->P.late_waves  = 0;
+    p->P.late_first  = 0;
     if (fused_cand && grid > 0) {
         const unsigned nw       = bthr / 64;
         // doubles per wave: transposition rows + window totals of the few-runs deposit for 2 pixel runs per tile (a pixel
         // has at least 64 rays) or 3, no row cache
-        const int maxq          = p->P.rays.nga * p->P.rays.ngb >= 64 ? 2 : 3;
-        const size_t per_wave   = (size_t) rt::fused_wave_doubles(maxq);
+        const bool emis         = p->P.use_emis != 0;
+        const int maxq          = emis && p->P.rays.nga * p->P.rays.ngb >= 64 ? 2 : 3;
+        // gain-only: rows of the per-wave row cache (a seeded tile holds ~7 pixels; fewer than 4 rows is not worth having)
+        int nslot               = emis ? 0 : (int) env_unsigned("RT_HIP_FUSED_ROWS", 7, 4, 16);
+        size_t per_wave         = (size_t) rt::fused_wave_doubles(maxq) + (size_t) nslot * (size_t) rt::freq_row_stride(p->P.Kp);
         rt::FusedLay lay;
         lay.off_exp  = (unsigned) align_up(p->P.blob_bytes, 16);
         lay.off_iang = lay.off_exp + 2u * rt::EXP_TAB * (unsigned) sizeof(double);
@@ -413,13 +428,23 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
                                                                                                           : (unsigned long long) p->cu_count;
             unsigned long long cap = wgs ? 2ull * ((unsigned long long) p->P.n_tiles / wgs + 1) + 32 : 64;
             cap           = cap < 64 ? 64 : (cap > 1024 ? 1024 : cap);
+            if (!emis) // (LDS is what the row caches are short of; the consumers keep the list short)
+                cap = cap > 256 ? 256 : cap;
             lay.node_cap  = env_unsigned("RT_HIP_FUSED_NODES", (unsigned) cap, 0, 4096);
         }
         lay.off_buf  = (unsigned) align_up(lay.off_nodes + lay.node_cap * 2u * (unsigned) sizeof(unsigned), 16);
+        size_t room = p->lds_limit > lay.off_buf ? (p->lds_limit - lay.off_buf) / (per_wave * sizeof(double)) : 0;
+        if (!emis && room < 5 && nslot > 5) { // one more buffer beside the tables is worth two rows of each cache
+            nslot    = 5;
+            per_wave = (size_t) rt::fused_wave_doubles(maxq) + (size_t) nslot * (size_t) rt::freq_row_stride(p->P.Kp);
+            room     = p->lds_limit > lay.off_buf ? (p->lds_limit - lay.off_buf) / (per_wave * sizeof(double)) : 0;
+        }
         lay.per_wave = (unsigned) per_wave;
-        const size_t room = p->lds_limit > lay.off_buf ? (p->lds_limit - lay.off_buf) / (per_wave * sizeof(double)) : 0;
-        lay.n_free        = (unsigned) (room < nw ? room : nw);
-        const bool fits   = 2 * lay.n_free >= nw && (size_t) (nw - lay.n_free) * per_wave * sizeof(double) <= p->P.blob_bytes;
+        lay.n_free   = (unsigned) (room < nw ? room : nw);
+        // emission: at least half the buffers beside the tables (the others overlay them once the march is over);
+        // gain-only: at least three, and they are the consumers'
+        const bool fits = (emis ? 2 * lay.n_free >= nw : (lay.n_free >= 3 && nw >= 8)) &&
+                          (size_t) (nw - lay.n_free) * per_wave * sizeof(double) <= p->P.blob_bytes;
         if (fits) {
             const size_t flds     = (size_t) lay.off_buf + (size_t) lay.n_free * per_wave * sizeof(double);
             const size_t n_tiles  = 4 * (size_t) p->P.n_tiles; // one link per (tile, part)
@@ -427,9 +452,10 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
             // worth it below 32 frequencies); RT_HIP_FUSED_SPLIT = 2: never, 3: every tile (tests)
             const unsigned split_env = env_unsigned("RT_HIP_FUSED_SPLIT", 1, 1, 3);
             lay.split  = split_env == 2 ? 0u : (split_env == 3 ? 2u : 1u);
-            lay.k_part = p->P.K >= 32 ? (unsigned) (((p->P.K + 3) / 4 + 3) / 4 * 4) : 0u;
-            // a quarter of the work-group -- its last, youngest waves, one per SIMD -- never marches (rt_fused.hip)
-            lay.n_consumers = env_unsigned("RT_HIP_FUSED_CONSUMERS", nw / 4, 0, nw > 1 ? nw - 1 : 0);
+            lay.k_part = p->P.K >= 32 && emis ? (unsigned) (((p->P.K + 3) / 4 + 3) / 4 * 4) : 0u;
+            // a quarter of the work-group -- its last, youngest waves, one per SIMD -- never marches (rt_fused.hip);
+            // gain-only: the same, all of them with a buffer beside the tables (four measured better than five or six)
+            lay.n_consumers = env_unsigned("RT_HIP_FUSED_CONSUMERS", emis ? nw / 4 : (lay.n_free < nw / 4 ? lay.n_free : nw / 4), 0, nw > 1 ? nw - 1 : 0);
             if (lay.n_consumers >= nw)
                 lay.n_consumers = nw - 1;
             lay.consumers_first = env_unsigned("RT_HIP_FUSED_CONSUMERS_FIRST", 0, 0, 1);
@@ -445,19 +471,25 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
             p->P.launch_id = 0;
             p->P.chunk     = (p->P.chunk + 32) / 64 * 64; // whole tiles per reservation (64 ... 192 rays)
             p->P.chunk     = p->P.chunk < 64 ? 64 : p->P.chunk;
-            late_zone(p, (unsigned) ((p->n_rays + bthr - 1) / bthr < (unsigned long long) p->cu_count ? (p->n_rays + bthr - 1) / bthr : p->cu_count), nw);
+            // (gain-only: the waves that run the frequency pass during the march are the youngest of their SIMD already,
+            // nothing starves the last marchers: no late zone)
+            if (emis)
+                late_zone(p, (unsigned) ((p->n_rays + bthr - 1) / bthr < (unsigned long long) p->cu_count ? (p->n_rays + bthr - 1) / bthr : p->cu_count),
+                          nw - lay.n_consumers, lay.consumers_first ? lay.n_consumers : 0u);
             p->P.tile_begin = 0;
             p->P.tile_end   = p->P.n_tiles;
             p->P.freq_id    = 0;
             rt::FusedKArg fa;
             fa.P         = p->P;
-            fa.F         = freq_args(p, true, 0, (unsigned long long) grid * nw);
+            fa.F         = freq_args(p, true, nslot, (unsigned long long) grid * nw);
             fa.tile_next = p->tile_next;
             fa.lay       = lay;
             const int S  = p->P.L * RT_N_SUB;
             using fused_fn = void (*)(const rt::FusedKArg);
             const fused_fn fk =
-                maxq == 2 ? (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 2> : rt::rt_fused_kernel<false, 6, 2>)
+                !emis     ? (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 3, false> : rt::rt_fused_kernel<false, 6, 3, false>)
+                                    : (bounded ? rt::rt_fused_kernel<true, 0, 3, false> : rt::rt_fused_kernel<false, 0, 3, false>))
+                : maxq == 2 ? (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 2> : rt::rt_fused_kernel<false, 6, 2>)
                                     : (bounded ? rt::rt_fused_kernel<true, 0, 2> : rt::rt_fused_kernel<false, 0, 2>))
                           : (S == 6 ? (bounded ? rt::rt_fused_kernel<true, 6, 3> : rt::rt_fused_kernel<false, 6, 3>)
                                     : (bounded ? rt::rt_fused_kernel<true, 0, 3> : rt::rt_fused_kernel<false, 0, 3>));

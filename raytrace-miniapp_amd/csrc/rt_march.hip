@@ -578,7 +578,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     // drain is run by one wave per SIMD that nothing on its SIMD outranks.  Zone 0: chunks [0, n_main), zone 1: the rest,
     // with counters of its own (next_tile[..][shard][8]).
     const unsigned n_main = n_chunks - (P.late_chunks < n_chunks ? P.late_chunks : 0u);
-    const bool late_wave  = (threadIdx.x >> 6) < P.late_waves;
+    const bool late_wave  = (threadIdx.x >> 6) - P.late_first < P.late_waves; // (unsigned: waves late_first .. late_first + late_waves - 1)
     unsigned zone = 0;
 
     // ---- per-lane state ----

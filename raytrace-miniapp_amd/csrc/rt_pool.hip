@@ -208,7 +208,7 @@ unsigned env_unsigned(const char *name, unsigned def, unsigned lo, unsigned hi)
     if (!e)
         return def;
     const long v = atol(e);
-    if (v <= 0)
+    if (v < 0 || (v == 0 && (lo > 0 || e[0] != '0'))) // (an explicit 0 counts where the range admits it; junk is the default)
         return def;
     return (unsigned) (v < (long) lo ? lo : (v > (long) hi ? hi : v));
 }

@@ -55,9 +55,8 @@ def test_one_launch_run_of_the_shipped_file_equals_the_reference_and_the_two_ker
 
 @pytest.mark.parametrize("scale", [0.25, 2.0, 16.0])
 def test_one_launch_run_on_scaled_problems_takes_every_work_group_size(hip, oracle, ase_small, scale):
-    """scale_problem (the reference's own enlargement rule, CreateImageHelpers.cpp:104-150): 0.25 -> 512-thread
-    work-groups with every transposition buffer beside the tables, 2 -> 768, 16 (the ASE_medium stand-in) -> 1024
-    threads, four waves with buffers that overlay the march tables."""
+    """scale_problem (the reference's own enlargement rule, CreateImageHelpers.cpp:104-150) at 0.25, 2 and 16 (the
+    ASE_medium stand-in): sixteen waves per work-group at every size since round 5, twelve of them marching."""
     p = rt.scale_problem(ase_small, scale)
     if p.beam.na * p.beam.nb < 32:
         pytest.skip("fewer than 32 rays per pixel: the run keeps two kernels")
@@ -229,3 +228,51 @@ def test_invalid_rays_are_reported_once_however_a_tile_is_split(hip, oracle, ase
     assert n_bad == 4 and len(one["failed_rays"]) == n_bad and len(two["failed_rays"]) == n_bad
     same_images(one, two, tol=1e-12)
     assert rel_l2(one["image"], ref["image"]) < TIGHT
+
+
+@pytest.mark.parametrize("env", [
+    {"RT_HIP_FUSED_CONSUMERS": "0", "RT_HIP_LATE_X10": "0"},                 # the round-4 run: every wave marches, no late zone
+    {"RT_HIP_FUSED_CONSUMERS": "4", "RT_HIP_LATE_X10": "0"},
+    {"RT_HIP_FUSED_CONSUMERS": "0", "RT_HIP_LATE_X10": "60"},
+    {"RT_HIP_FUSED_CONSUMERS": "7", "RT_HIP_LATE_X10": "1000", "RT_HIP_LATE_WAVES": "1"},   # a quarter of the list for one wave
+    {"RT_HIP_FUSED_NODES": "0"},                                             # every list entry takes the global links
+    {"RT_HIP_FUSED_NODES": "3"},                                             # LDS nodes and overflow mixed on one stack
+    {"RT_HIP_FUSED_CONSUMERS_FIRST": "1"},
+    {"RT_HIP_MARCH_THREADS": "256", "RT_HIP_FUSED_CONSUMERS": "1"},
+    {"RT_HIP_MARCH_THREADS": "64"},                                          # one wave per work-group: it marches, then consumes
+])
+def test_consumer_waves_late_zone_and_list_storage_leave_the_image_alone(hip, oracle, ase_small, env, monkeypatch):
+    """Round 5 of the one-launch run: waves that only run the frequency pass (consumers), the end of the ray list kept
+    for the first waves of each work-group (late zone), list nodes in LDS with overflow to global links -- whatever the
+    mix, every ray is marched once and every tile integrated once: counters and image of the two-kernel run."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 64 * 1500 + 17
+    one, two = run_grid(hip, ase_small, True, count=n), run_grid(hip, ase_small, False, count=n)
+    assert one["fused"] and not two["fused"]
+    assert one["stats"]["n_rays"] == n
+    same_images(one, two, tol=1e-12)
+    whole = run_grid(hip, ase_small, True)
+    assert whole["stats"]["cell_steps"] == 4768067 and whole["failure_code"] == 0
+
+
+def test_seeded_mode_as_one_launch(hip, seed_small, seed_ref, monkeypatch):
+    """The gain-only instance of the one-launch kernel (RT_HIP_FUSED_SEED=1; two kernels are the rule for this mode,
+    profiles/r05_seed_fused_ab.txt): row caches for the consumers beside the tables, for the others over them once the
+    march is done.  seed_small.dat against the reference's CPU loop and against the two-kernel run."""
+    two = run_grid(hip, seed_small, True)
+    assert not two["fused"]
+    monkeypatch.setenv("RT_HIP_FUSED_SEED", "1")
+    for extra in ({}, {"RT_HIP_FUSED_CONSUMERS": "2", "RT_HIP_FUSED_ROWS": "5"}, {"RT_HIP_FUSED_NODES": "0"}):
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        one = run_grid(hip, seed_small, True)
+        assert one["fused"]
+        assert one["stats"]["n_rays"] == 7803000 and one["stats"]["cell_steps"] == 53573880
+        assert rel_l2(one["image"], seed_ref["image"]) < 1e-12 and rel_l2(one["I_ang"], seed_ref["I_ang"]) < 1e-12
+        same_images(one, two, tol=1e-12)
+        for k in extra:
+            monkeypatch.delenv(k)
+    part = run_grid(hip, seed_small, True, count=64 * 3000 + 5)
+    monkeypatch.delenv("RT_HIP_FUSED_SEED")
+    same_images(part, run_grid(hip, seed_small, True, count=64 * 3000 + 5), tol=1e-12)

@@ -33,6 +33,10 @@ for case in cases:
         p = full
     elif case == "seed":
         p = rt.datfile.load('tests/golden/seed_small.dat.xz')
+    elif case == "seedmed":
+        p = rt.scale_problem(rt.datfile.load('tests/golden/seed_small.dat.xz'), 16.0)
+    elif case.startswith("seedx"):
+        p = rt.scale_problem(rt.datfile.load('tests/golden/seed_small.dat.xz'), float(case[5:]))
     else:
         n = int(case[5:].split(".")[0]); r = int(case.split(".")[1]) if "." in case else 0
         p = mg.shard(full, r, n)
