@@ -266,12 +266,13 @@ int plan_repeat_checked(rt_hip_plan *p)
 // The chunks at the end of the ray list that only the oldest wave of every SIMD takes (rt_march.hip, "The end of a
 // launch"): about as many rays as those waves march in one drain period, RT_HIP_LATE_X10 tenths of a ray per lane of
 // theirs (0: no such zone), at most a quarter of the launch.
-static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg, unsigned first_marching_wave)
+static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg, unsigned first_marching_wave, const char *env = "RT_HIP_LATE_X10",
+                      unsigned def_x10 = 32)
 {
     // (the waves that take the late chunks must be waves that march: waves_per_wg counts the marching waves,
     // first_marching_wave is where they start inside the work-group)
     p->P.late_first = first_marching_wave;
-    const unsigned x10   = env_unsigned("RT_HIP_LATE_X10", 32, 0, 1000);
+    const unsigned x10   = env_unsigned(env, def_x10, 0, 1000);
     const unsigned waves = env_unsigned("RT_HIP_LATE_WAVES", 4, 0, 16);
     p->P.late_waves  = waves < waves_per_wg ? waves : waves_per_wg;
     p->P.late_chunks = 0;
@@ -532,6 +533,10 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
         p->P.ray_begin = (unsigned) b;
         p->P.ray_end   = (unsigned) e;
         p->P.launch_id = c;
+        // (the march as a kernel of its own: the end of the list for the oldest wave of every SIMD as well -- its tail is the
+        // drain of the last rays, and one wave per SIMD runs it at the pace of a wave that has the SIMD to itself)
+        if (n_launch == 1 && lds_tab)
+            late_zone(p, grid, bthr / 64, 0u, "RT_HIP_LATE2_X10", 60); // (seed_small -0.8 %, stand-in as two kernels -1.5 %, its 8-rank shard -6 %)
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(bthr), mlds, stream, p->P);
         HIP_TRY(hipGetLastError());
     }
