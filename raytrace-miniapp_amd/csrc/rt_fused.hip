@@ -68,6 +68,10 @@ template <bool BOUNDED, int SF, int MAXQ, bool EMIS = true>
 __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+#ifdef RT_WAVETIMES
+    if (threadIdx.x == 0)
+        atomicMin(&g_wt[2], __builtin_amdgcn_s_memrealtime()); // the first work-group to start: t = 0 of the launch
+#endif
     const FreqHot &H   = A.F.hot;
     const int n_ang    = H.n_ang;
     double *exp2_tab   = reinterpret_cast<double *>(lds_raw + A.lay.off_exp);

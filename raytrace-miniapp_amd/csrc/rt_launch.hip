@@ -265,7 +265,8 @@ int plan_repeat_checked(rt_hip_plan *p)
 
 // The chunks at the end of the ray list that only the oldest wave of every SIMD takes (rt_march.hip, "The end of a
 // launch"): about as many rays as those waves march in one drain period, RT_HIP_LATE_X10 tenths of a ray per lane of
-// theirs (0: no such zone), at most a quarter of the launch.
+// theirs (0: no such zone), at most RT_HIP_LATE_CAP per cent of the launch (20: swept 8 ... 35 on the 8- and 16-rank shards and
+// ASE_small.dat, profiles/r05_fused_end.txt).
 static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg, unsigned first_marching_wave, const char *env = "RT_HIP_LATE_X10",
                       unsigned def_x10 = 32)
 {
@@ -279,7 +280,8 @@ static void late_zone(rt_hip_plan *p, unsigned grid, unsigned waves_per_wg, unsi
     if (x10 == 0 || p->P.late_waves == 0 || p->P.chunk == 0)
         return;
     unsigned long long rays = (unsigned long long) grid * p->P.late_waves * 64ull * x10 / 10ull;
-    rays                    = rays > p->n_rays / 4 ? p->n_rays / 4 : rays;
+    const unsigned long long cap = p->n_rays * env_unsigned("RT_HIP_LATE_CAP", 20, 0, 100) / 100ull; // (per cent of the launch)
+    rays                    = rays > cap ? cap : rays;
     p->P.late_chunks        = (unsigned) (rays / p->P.chunk);
 }
 

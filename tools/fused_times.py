@@ -26,6 +26,10 @@ for name, p in (("N=1", full), ("N=8 shard", mg.shard(full, 0, 8)), ("ASE_small.
     wg = (F[4] & np.uint64(0xffff)).astype(np.int64); tiles = F[5].astype(np.int64)
     dry = (np.array(d[:int(list(s)[6])], dtype=np.float64) - t0) / 100.0
     print(f"{name}: launch {st['march_ms']:.3f} ms, waves {n}")
+    k0 = list(s)[2]
+    if k0 and k0 != 0xffffffffffffffff:
+        print(f"   first work-group enters the kernel {(t0 - k0) / 100.0:.1f} us before the first wave starts marching; "
+              f"last wave starts marching at {(list(s)[1] - k0) / 100.0:.1f} us")
     pc = lambda a: " ".join(f"{x:7.0f}" for x in np.percentile(a, [0, 10, 50, 90, 100]))
     print(f"   counters dry (us)      min/10/50/90/max: {pc(dry)}")
     print(f"   wave leaves the march  min/10/50/90/max: {pc(left)}")
