@@ -204,3 +204,8 @@ def test_bench_two_rank_launch_rehearsal(hip):
     assert cab["entry"] == "rt_hip_multi_image_loop" and cab["ndev"] == 2 and "tiles" in cab["mode"]
     assert cab["image_matches_single_device_1e-12"] and cab["ray_steps"] == 75601675 and cab["failure_code"] == 0
     assert cab["ms_per_image"] > 0 and cab["kernel_ms_max_over_devices"] > 0
+    # no fraction above 1 anywhere in the line (contract_frac is the formula's figure and may exceed it)
+    from test_host_logic import _fracs
+    for path, v in _fracs(line):
+        assert v is None or v <= 1.0, (path, v)
+    assert line["warmup"] == 1 and line["warmup_requested"] == 1

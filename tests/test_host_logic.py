@@ -312,3 +312,41 @@ def test_bench_accounting_of_the_contract_formula():
     assert abs(a["path"] - 962e6) < 1e6 and a["write"] == 8 * (60 * 25 * 52 + 19 * 14)
     s = bench.algorithmic_bytes(7803000, 53573880, 2, 82, True, 6907454, 1500, 266)
     assert abs(s["path"] - 26.1e9) < 0.5e9
+
+
+def _fracs(node, path=""):
+    """Every (path, value) of a key named `frac` / ending in `_frac` in a nested record."""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if (k == "frac" or k.endswith("_frac")) and not k.endswith("contract_frac") and k != "raw_frac":
+                yield path + "/" + k, v
+            yield from _fracs(v, path + "/" + k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            yield from _fracs(v, f"{path}[{i}]")
+
+
+def test_bench_sub_records_never_show_a_fraction_above_one():
+    """bench.py's `bounded_roof`: the contract formula's figure (algorithmic bytes over time over the HBM peak) exceeds 1
+    where the caches serve the bytes; it is `contract_frac`.  `frac` is measured HBM traffic against the peak, the contract
+    figure only while that is below 1, else null; `issue_frac` comes from the SQ pass.  """
+    import importlib.util
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("bench_module", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules["bench_module"] = bench
+    spec.loader.exec_module(bench)
+    hot = bench.bounded_roof(220.5e9, 26.2e-3)                      # config 5 by the formula: 1.05
+    assert hot["contract_frac"] > 1.0 and hot["frac"] is None and hot["achieved"] is None
+    meas = bench.bounded_roof(220.5e9, 26.2e-3, traffic=75.5e9)     # ... and by its measured traffic: 0.36
+    assert meas["contract_frac"] > 1.0 and 0.3 < meas["frac"] < 0.4 and "measured" in meas["achieved_basis"]
+    cool = bench.bounded_roof(15.33e9, 2.7e-3)
+    assert cool["frac"] == cool["contract_frac"] and 0.69 < cool["frac"] < 0.72
+    sq = {"avg": {"SQ_INSTS_VALU": 13.9e9, "SQ_INSTS_SALU": 0.8e9}}
+    iss = bench.bounded_roof(206e9, 22e-3, None, sq, 2.28e9)
+    assert 0.5 < iss["issue_frac"] < 0.7 and iss["issue"]["unit"] == "G wave-instr/s"
+    for rec in (hot, meas, cool, iss):
+        for path, v in _fracs(rec):
+            assert v is None or v <= 1.0, (path, v)
