@@ -633,10 +633,20 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     // and, with P.express_hold, stops fetching rays from the counters while it does: its short rays retire, fewer lanes
     // mean fewer of the three blocks per iteration, and the long rays it holds advance at the pace of a wave that has
     // its SIMD to itself.  Looked at every fourth iteration; everything here is wave-uniform.
-    unsigned wave_iter = 0, born = 0;
+    // (Measured in round 5, profiles/r05_express_ab.txt: +-1 ... 5 % -- what ends a launch is not the old rays, rt_fused.hip.
+    // The code is compiled only into the diagnostic build librt_hip_express.so, -DRT_EXPRESS: the loop head is sensitive to
+    // every instruction.)
+#if defined(RT_EXPRESS) || defined(RT_WAVETIMES)
+    unsigned wave_iter = 0;
+#endif
+#ifdef RT_EXPRESS
+    unsigned born = 0;
     bool old_wave = false;
     if (P.express_tail == 1u)
         __builtin_amdgcn_s_setprio(2);
+#else
+    constexpr bool old_wave = false;
+#endif
     for (;;) {
         RT_MARK(5); // [C] of the previous iteration
 #ifdef RT_INSTRUMENT
@@ -650,7 +660,9 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         const int n_idle              = (int) __popcll(idle);
         if (n_idle == WAVE && !more)
             break;
+#if defined(RT_EXPRESS) || defined(RT_WAVETIMES)
         wave_iter++;
+#endif
 #ifdef RT_WAVETIMES
         if ((wave_iter & 15u) == 0u) {
             const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), smp = wave_iter >> 4;
@@ -670,6 +682,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
             wt_a_runs = wt_b_runs = 0;
         }
 #endif
+#ifdef RT_EXPRESS
         if (P.express_age != 0u && (wave_iter & 3u) == 0u) {
             const bool o = __ballot(st != ST_IDLE && wave_iter - born > P.express_age) != 0ull;
             if (o != old_wave) {
@@ -680,6 +693,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                     __builtin_amdgcn_s_setprio(0);
             }
         }
+#endif
         // Watchdog of the instance that takes tables and step sizes as they come (BOUNDED = false: something is outside
         // the ranges rt_hip_plan_create verifies -- an index far from 1, a gradient beyond 1e12, a dz beyond 1e6 cm).
         // The reference's loops have no iteration limit, and with such inputs a ray's steps can stop advancing (an
@@ -707,8 +721,10 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
             bool got = false;
             while (need > 0) {
                 if (chunk_next == chunk_end && !(FUSED && chunk_next != fetched_end)) {
+#ifdef RT_EXPRESS
                     if (old_wave && P.express_hold != 0u)
                         break; // an express wave takes no new reservation (what it has reserved it still hands out)
+#endif
                     unsigned c = 0;
 #ifdef RT_MARCH_ONE_COUNTER // experiment: one counter for all waves
                     if (lane == 0)
@@ -728,8 +744,10 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                                 continue;
                             }
                             more = false;
+#ifdef RT_EXPRESS
                             if (P.express_tail == 2u)
                                 __builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef RT_WAVETIMES
                             wt_dry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -825,7 +843,9 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 any_bits  = 0;
                 sub       = 0;
                 st        = ST_CELL;
+#ifdef RT_EXPRESS
                 born      = wave_iter;
+#endif
             }
         }
         // (at this point every lane is idle, waits for [A], or is in [B] / [C]: the three lane masks the loop
@@ -857,8 +877,10 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
             park_at          = fifth < (int) P.park ? fifth : (int) P.park;
             // an express wave holds long rays only: most of their iterations are integrator steps inside one cell, so
             // [A] is worth deferring much longer than in a wave of average rays (P.express_park 64ths of the live lanes)
+#ifdef RT_EXPRESS
             if (old_wave && P.express_park != 0u)
                 park_at = (n_live * (int) P.express_park + 63) >> 6;
+#endif
         }
         const bool do_a = (int) __popcll(want_a) >= park_at || (~(idle2 | want_a)) == 0ull;
         bool last_of_tile = false; // FUSED: the lane's ray ends in this iteration and was the last one of its tile
@@ -1226,8 +1248,10 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         }
         } // some lane is marching
     }
+#ifdef RT_EXPRESS
     if (P.express_age != 0u || P.express_tail != 0u)
         __builtin_amdgcn_s_setprio(0);
+#endif
 
 #ifdef RT_WAVETIMES
     if (lane == 0) {
