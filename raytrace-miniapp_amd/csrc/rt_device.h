@@ -10,7 +10,7 @@
 //   gv[Nx*Ny][K] float per length: lineshape rows, k fastest (frequency kernel)
 //   beam grids x,y,a,b,dv (double), seed tables (double), tangent tables,
 //   the ray list (16 B/ray) when rays are given explicitly,
-//   march records (96 B/ray for N = 3) between the two kernels.
+//   march records (96 B/ray for N = 3, tile-wise: 64 rays share a block) between the two kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -103,10 +103,16 @@ struct DevRays {
     unsigned div_mul[3], div_sh[3];
 };
 
-// Per-ray march record, one per ray at rec + ridx * rec_stride:
+// Per-ray march record: S slots + one meta block,
 //   RecSlot slot[S];    {gvl, evl, ivl} of each sub-segment, S = (N-1)*3, Helper.h:386-388
 //                       (one 12-byte store when a sub-segment ends)
 //   RecMeta meta;       exit position / direction, flags | n_done << 4 | steps << 12
+// laid out TILE-WISE since round 5: the 64 rays 64 t .. 64 t + 63 (a tile of the frequency pass) share a block of
+// 64 * rec_stride bytes at rec + t * 64 * rec_stride, slot s of ray 64 t + l at s * 768 + l * 12 inside it, the meta block
+// of that ray at S * 768 + l * 24 (rec_slot_off / rec_meta_off below).  The frequency pass reads slot s of its 64 lanes
+// as ONE contiguous 768-byte run (round 4: 12 bytes every 96), and the 32-byte sector a slot store of the march lands in holds
+// the same slot of the neighbouring rays -- rays a launch angle apart, which end that sub-segment within a few iterations
+// of each other and merge in L2 -- instead of the ray's own other slots, written tens of microseconds apart.
 // Only the first n_done sub-segments in marching order were entered and have their slot written
 // (an escaped ray stops early, Helper.h:465-469, 505-511); readers take the others as zero:
 // rec_slot() below.  Forward march: slots 0 .. n_done-1, backward: S-n_done .. S-1.
@@ -289,16 +295,34 @@ enum : unsigned {
     F_VALID   = 8u  // lane holds a ray of this tile
 };
 
-// slot s of a record, zero if the ray never entered that sub-segment
 #ifdef __HIPCC__
-__host__ __device__
+#define RT_HD __host__ __device__
+#else
+#define RT_HD
 #endif
-inline RecSlot rec_slot(const unsigned char *rec, int s, int S, unsigned flags_steps, bool backward)
+constexpr unsigned REC_SLOT_ROW = WAVE * 12u; // bytes of one slot of the 64 rays of a tile
+// byte offsets of slot s / of the meta block of ray ridx from the start of the record buffer
+RT_HD inline size_t rec_slot_off(unsigned ridx, int s, unsigned rec_stride)
+{
+    return (size_t) (ridx >> 6) * ((size_t) WAVE * rec_stride) + (size_t) s * REC_SLOT_ROW + (size_t) (ridx & 63u) * 12u;
+}
+RT_HD inline size_t rec_meta_off(unsigned ridx, int S, unsigned rec_stride)
+{
+    return (size_t) (ridx >> 6) * ((size_t) WAVE * rec_stride) + (size_t) S * REC_SLOT_ROW + (size_t) (ridx & 63u) * sizeof(RecMeta);
+}
+// bytes of the record buffer of n_rays rays (whole tiles)
+RT_HD inline size_t rec_bytes(unsigned long long n_rays, unsigned rec_stride)
+{
+    return (size_t) ((n_rays + WAVE - 1) / WAVE) * ((size_t) WAVE * rec_stride);
+}
+// slot s of the record of ray ridx (rec = start of the record buffer), zero if the ray never entered that sub-segment
+RT_HD inline RecSlot rec_slot(const unsigned char *rec, unsigned ridx, unsigned rec_stride, int s, int S, unsigned flags_steps,
+                              bool backward)
 {
     const int n_done   = (int) ((flags_steps >> REC_NDONE_SHIFT) & REC_NDONE_MASK);
     const bool written = backward ? s >= S - n_done : s < n_done;
     RecSlot z          = { 0.0f, 0.0f, 0 };
-    return written ? reinterpret_cast<const RecSlot *>(rec)[s] : z;
+    return written ? *reinterpret_cast<const RecSlot *>(rec + rec_slot_off(ridx, s, rec_stride)) : z;
 }
 
 } // namespace rt

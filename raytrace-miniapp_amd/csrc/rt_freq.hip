@@ -450,7 +450,9 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     const unsigned ridx   = tile * WAVE + (unsigned) lane;
     const bool have       = ridx < n_rays;
     const bool backward   = H.method == 1;
-    const unsigned char *rec = H.rec + (size_t) (have ? ridx : 0) * H.rec_stride;
+    // (records are tile-wise, rt_device.h: slot s of the 64 lanes is one contiguous run)
+    const unsigned rrec      = have ? ridx : 0u;
+    const unsigned char *rec = H.rec;
     constexpr bool use_emis = EMIS; // Helper.h:402, fixed per kernel instance (see launch_freq)
     const bool safe_check = (hflags & FQ_SAFE_CHECK) != 0, safe_skip = (hflags & FQ_SAFE_SKIP) != 0;
     const bool probe_on   = (hflags & FQ_PROBE) != 0;
@@ -475,11 +477,12 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
     const bool own = (hflags & FQ_OWN_CELLS) != 0;
     const bool need_ray = !own || probe_on; // (a failing own-cell ray loads its start ray when it is reported)
     if (have) {
-        m = *reinterpret_cast<const RecMeta *>(rec + 12 * (size_t) S);
+        m = *reinterpret_cast<const RecMeta *>(rec + rec_meta_off(rrec, S, H.rec_stride));
         if (SF) {
+            const unsigned char *slot0 = rec + rec_slot_off(rrec, 0, H.rec_stride);
 #pragma unroll
             for (int s = 0; s < SF; s++)
-                raw[s] = reinterpret_cast<const RecSlot *>(rec)[s];
+                raw[s] = *reinterpret_cast<const RecSlot *>(slot0 + (size_t) s * REC_SLOT_ROW);
         }
         if (need_ray) {
             float ta, tb;
@@ -677,7 +680,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                         if (fabsf(gs[s]) >= RT_RS_MIN && fabsf(gs[s]) <= H.gs_cap && !exact_emis) {
                             ase_step(Iv, gs[s], rs[s], w[s].v, tab);
                         } else {
-                            const float e1 = rec_slot(rec, s, SF, m.flags_steps, backward).e;
+                            const float e1 = rec_slot(rec, rrec, H.rec_stride, s, SF, m.flags_steps, backward).e;
                             if (gs[s] != 0.0f || e1 != 0.0f) { // else the update is the identity
 #pragma unroll
                                 for (int j = 0; j < VEC; j++)
@@ -701,7 +704,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                     for (int j = 0; j < VEC; j++)
                         wnan[j] = false;
                     for (int s = 0; s < S; s++) {
-                        const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, backward);
+                        const RecSlot sl = rec_slot(rec, rrec, H.rec_stride, s, S, m.flags_steps, backward);
                         const float g1 = sl.g, e1 = sl.e;
                         const int c1   = sl.c;
                         const float *row  = H.gain[s / RT_N_SUB + 1].gv + (size_t) c1 * (size_t) Kp + kb;
@@ -739,7 +742,7 @@ __device__ __forceinline__ void freq_tile(const FreqHot &H, const unsigned hflag
                     }
                 } else {
                     for (int s = 0; s < S; s++) {
-                        const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, backward);
+                        const RecSlot sl = rec_slot(rec, rrec, H.rec_stride, s, S, m.flags_steps, backward);
                         const float *row = H.gain[s / RT_N_SUB + 1].gv + (size_t) sl.c * (size_t) Kp + kb;
                         const FVec w     = *reinterpret_cast<const FVec *>(row);
 #pragma unroll

@@ -120,7 +120,8 @@ template <int SF, bool EMIS, bool EXCL> int launch_freq(rt_hip_plan *p, hipStrea
     int nslot = 0;
     if (!excl) { // (exclusive mode: no reduction at all; the space holds the store staging rows instead)
         nslot = rows_that_fit(p->lds_limit / (size_t) wg_per_cu);
-        if (!EMIS && nslot < 7 && wg_per_cu > 1) { // seeded tiles hold ~7 pixels: rather one work-group less per CU than no row for them
+        const int min_rows = (int) env_unsigned("RT_HIP_FREQ_MIN_ROWS", 7, 0, 16);
+        if (!EMIS && nslot < min_rows && wg_per_cu > 1) { // seeded tiles hold ~7 pixels: rather one work-group less per CU than no row for them
             wg_per_cu--;
             nslot = rows_that_fit(p->lds_limit / (size_t) wg_per_cu);
         }
@@ -292,7 +293,7 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     // the kernels index rays with 32 bits and round the ray count up to whole chunks of at most 4096 rays
     if (p->n_rays > (unsigned long long) MAX_LIST_RAYS)
         return fail_arg("more than 2^32 - 4096 rays in one run");
-    const size_t need = (size_t) p->n_rays * p->P.rec_stride;
+    const size_t need = rt::rec_bytes(p->n_rays, p->P.rec_stride); // (whole 64-ray tiles: the records are tile-wise)
     if (need > p->rec_bytes || !p->rec) {
         plan_quiesce(p);
         pool_free(p->device, p->rec);

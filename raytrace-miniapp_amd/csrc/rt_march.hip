@@ -590,6 +590,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     float gacc = 0, eacc = 0;
     int cell_last = 0, sub = 0; // sub: sub-segments committed so far (slots written), 0 .. S
     unsigned char *recp = P.rec; // slot of the lane's current sub-segment inside its ray's record
+    unsigned lane12     = 0;     // 12 x (the ray's place in its tile): what the meta block lies beyond the tile's slot rows
     BlobGain G    = hdr[1]; // header of the lane's current length ii, re-read only when ii changes
     unsigned steps = 0;
     bool escaped = false, mirror = false;
@@ -825,7 +826,8 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                     pp[1]     = py;
                 }
                 // the record's slots are visited in marching order: up from slot 0, or down from slot S-1
-                recp      = P.rec + (size_t) ridx * P.rec_stride + (backward ? 12 * (S - 1) : 0);
+                recp      = P.rec + rec_slot_off(ridx, backward ? S - 1 : 0, P.rec_stride);
+                lane12    = (ridx & 63u) * 12u; // (kept for the meta store at retirement: that block runs in almost every iteration)
                 seg       = 0;
                 iz        = 0;
                 ii        = backward ? P.N - 1 : 1;
@@ -896,7 +898,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
 #ifndef RT_ABL_NOSTORE
                 *reinterpret_cast<RecSlot *>(recp) = RecSlot{ gacc, eacc, cell_last };
 #endif
-                recp += backward ? -12 : 12;
+                recp += backward ? -(int) REC_SLOT_ROW : (int) REC_SLOT_ROW; // the same ray's next slot: one slot row on
                 any_bits |= (__float_as_uint(gacc) | __float_as_uint(eacc)) & 0x7fffffffu;
                 if (P.path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
                                  // segment records the same position, later segments stay zero
@@ -1053,13 +1055,14 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 // (the per-ray step count of the record saturates at 2^20 - 1; the launch total below is exact)
                 m.flags_steps = fl | ((unsigned) sub << REC_NDONE_SHIFT) |
                                 ((steps < 0xfffffu ? steps : 0xfffffu) << REC_STEPS_SHIFT);
-                // `sub` slots were committed: recp stands that many slots above slot 0 (forward) or below
-                // slot S-1 (backward); the meta block follows slot S-1
+                // `sub` slots were committed: recp stands that many slot rows above slot 0 (forward) or below
+                // slot S-1 (backward); the meta blocks of the tile follow slot row S-1, 24 bytes per ray where a slot has 12
+                unsigned char *metap = recp + (int) REC_SLOT_ROW * (backward ? sub + 1 : S - sub) + lane12;
 #ifndef RT_ABL_NOMETA
-                *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? sub + 1 : S - sub)) = m;
+                *reinterpret_cast<RecMeta *>(metap) = m;
 #else
                 if (m.px == 1234.5f) // profiling only: the store stays reachable, but never happens
-                    *reinterpret_cast<RecMeta *>(recp + 12 * (backward ? sub + 1 : S - sub)) = m;
+                    *reinterpret_cast<RecMeta *>(metap) = m;
 #endif
 #ifdef RT_INSTRUMENT
                 if (ridx < (1u << 23))

@@ -18,8 +18,8 @@ extern "C" __global__ void __launch_bounds__(256) rt_path_kernel(const DevParams
         return;
     const int S  = P.L * RT_N_SUB;
     const int K  = P.K;
-    const unsigned char *rec = P.rec + (size_t) ridx * P.rec_stride;
-    const RecMeta m = *reinterpret_cast<const RecMeta *>(rec + 12 * (size_t) S);
+    const unsigned char *rec = P.rec; // (tile-wise records, rt_device.h)
+    const RecMeta m = *reinterpret_cast<const RecMeta *>(rec + rec_meta_off(ridx, S, P.rec_stride));
     const unsigned fl = m.flags_steps & REC_FLAG_MASK;
     float *dbg        = P.path + (size_t) ridx * 3 * (size_t) (S + 1);
     if ((double) (m.sz * m.sz) < 0.01) { // Helper.h:515: positions only
@@ -45,7 +45,7 @@ extern "C" __global__ void __launch_bounds__(256) rt_path_kernel(const DevParams
         const double dvk = P.beam.dv[k];
         dbg[2] += (float) (2 * Iv * dvk); // Helper.h:536-542
         for (int s = 0; s < S; s++) {     // Helper.h:543-566: emission formula per sub-segment
-            const RecSlot sl = rec_slot(rec, s, S, m.flags_steps, P.method == 1);
+            const RecSlot sl = rec_slot(rec, ridx, P.rec_stride, s, S, m.flags_steps, P.method == 1);
             const float gs = sl.g, es = sl.e;
             const int cell = sl.c;
             const float w   = P.gain[s / RT_N_SUB + 1].gv[(size_t) cell * (size_t) P.Kp + (size_t) k];

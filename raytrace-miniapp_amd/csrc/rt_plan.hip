@@ -1063,14 +1063,14 @@ int rt_hip_plan_fetch_probe(rt_hip_plan *p, float *gvl, float *evl, int32_t *ivl
     const size_t n = (size_t) p->n_rays, S = (size_t) p->P.L * RT_N_SUB;
     {
         // the march records themselves are the probe: de-interleave them
-        std::vector<unsigned char> h(n * p->P.rec_stride);
+        std::vector<unsigned char> h(rt::rec_bytes(n, p->P.rec_stride));
         if (n)
             HIP_TRY(hipMemcpy(h.data(), p->rec, h.size(), hipMemcpyDeviceToHost));
         for (size_t r = 0; r < n; r++) {
-            const unsigned char *rec = h.data() + r * p->P.rec_stride;
-            const rt::RecMeta *mt = reinterpret_cast<const rt::RecMeta *>(rec + 12 * S);
+            const unsigned char *rec = h.data();
+            const rt::RecMeta *mt = reinterpret_cast<const rt::RecMeta *>(rec + rt::rec_meta_off((unsigned) r, (int) S, p->P.rec_stride));
             for (size_t q = 0; q < S; q++) {
-                const rt::RecSlot sl = rt::rec_slot(rec, (int) q, (int) S, mt->flags_steps, p->P.method == 1);
+                const rt::RecSlot sl = rt::rec_slot(rec, (unsigned) r, p->P.rec_stride, (int) q, (int) S, mt->flags_steps, p->P.method == 1);
                 if (gvl)
                     gvl[r * S + q] = sl.g;
                 if (evl)
