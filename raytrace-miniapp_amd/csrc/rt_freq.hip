@@ -996,7 +996,7 @@ __global__ void __launch_bounds__(FREQ_WG_WAVES * 64, EMIS ? RT_FREQ_WAVES : RT_
     double *lds_iang       = iang_in_lds ? exp2_tab + 2 * EXP_TAB : nullptr;
     double *waves_base     = exp2_tab + 2 * EXP_TAB + (iang_in_lds ? ((n_ang + 1) & ~1) : 0);
     const size_t per_wave  = excl ? (size_t) WAVE * XS_ROW : (size_t) FREQ_WAVE_XPOSE + (size_t) nslot * (size_t) freq_row_stride(H.Kp);
-    double *mine           = waves_base + (size_t) (threadIdx.x >> 6) * per_wave;
+    double *mine           = waves_base + (size_t) (unsigned) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) * per_wave;
     double *xpose          = mine; // (not used in exclusive mode)
     double *cache          = excl ? mine : mine + FREQ_WAVE_XPOSE;
     for (size_t c = threadIdx.x; c < (size_t) (blockDim.x >> 6) * per_wave; c += blockDim.x)

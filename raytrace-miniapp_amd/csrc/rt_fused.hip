@@ -82,7 +82,9 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     const unsigned n_march  = n_waves - A.lay.n_consumers; // waves 0 .. n_march-1 march, the others only consume
     // (which waves: the instruction arbiter of a SIMD serves its OLDEST waves first -- the lowest wave numbers of the
     // work-group -- whatever s_setprio says; consumers_first makes the consumers those waves)
-    const bool consumer     = A.lay.consumers_first ? (threadIdx.x >> 6) < A.lay.n_consumers : (threadIdx.x >> 6) >= n_march;
+    // (the wave's number through readfirstlane: wave-uniform for the compiler too, not only in fact)
+    const unsigned wave_id  = (unsigned) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const bool consumer     = A.lay.consumers_first ? wave_id < A.lay.n_consumers : wave_id >= n_march;
     // (everything below lies behind the march tables: the copy of the tables at the head of march_wave ends in the
     // barrier that also publishes these)
     for (unsigned c = threadIdx.x; c < A.lay.n_free * A.lay.per_wave; c += blockDim.x)
@@ -94,6 +96,9 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     }
     for (int c = (int) threadIdx.x; c < n_ang; c += (int) blockDim.x)
         lds_iang[c] = 0.0;
+    // (the tile counters of every wave start at zero = free, rt_march.hip)
+    for (unsigned c = threadIdx.x; c < n_waves * 32u; c += blockDim.x)
+        reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem)[c] = 0u;
     if (threadIdx.x == 0) {
         ctl[0] = TILE_NONE;
         ctl[1] = n_march;
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
         ctl[3] = 0u;
     }
     const TileList list{ &ctl[0], A.tile_next, reinterpret_cast<unsigned *>(lds_raw + A.lay.off_nodes), &ctl[3], A.lay.node_cap,
-                         reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + (threadIdx.x >> 6) * 32u,
+                         reinterpret_cast<unsigned *>(lds_raw + A.lay.off_rem) + wave_id * 32u,
                          &ctl[1], n_march, A.lay.split, A.lay.k_part };
 
     // ---- phase 1: the march (rt_march.hip), one tile per chunk, finished tiles pushed onto the list ----

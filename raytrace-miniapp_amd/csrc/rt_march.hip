@@ -578,7 +578,10 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     // drain is run by one wave per SIMD that nothing on its SIMD outranks.  Zone 0: chunks [0, n_main), zone 1: the rest,
     // with counters of its own (next_tile[..][shard][8]).
     const unsigned n_main = n_chunks - (P.late_chunks < n_chunks ? P.late_chunks : 0u);
-    const bool late_wave  = (threadIdx.x >> 6) - P.late_first < P.late_waves; // (unsigned: waves late_first .. late_first + late_waves - 1)
+    // (unsigned: waves late_first .. late_first + late_waves - 1; through readfirstlane, so that the compiler knows it for
+    // wave-uniform -- derived from threadIdx.x it counts as divergent, and with it `zone`, `more` and every branch of the
+    // loop head that tests them, which then run as exec-mask code instead of scalar branches)
+    const bool late_wave  = (unsigned) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) - P.late_first < P.late_waves;
     unsigned zone = 0;
 
     // ---- per-lane state ----
@@ -766,6 +769,12 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 }
                 if (FUSED && chunk_next == chunk_end) {
                     // open the next tile of the reservation: a free counter slot, loaded with the tile's ray count
+#ifndef RT_FUSED_PUBLISH_WAVE
+                    // (a slot is free when its counter is back at zero: the lane that took it there published the tile in
+                    // the same breath, below; looked up here, once per tile, instead of being tracked in every iteration)
+                    const unsigned in_use = lane < 32 ? __hip_atomic_load(&done.rem[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 1u;
+                    slot_busy             = ~(unsigned) __ballot(lane < 32 && in_use == 0u);
+#endif
                     const int fs = __builtin_ffs((int) ~slot_busy) - 1;
                     if (fs < 0)
                         break; // 32 tiles of this wave in flight (never observed): no new rays until one completes
@@ -885,7 +894,9 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
 #endif
         }
         const bool do_a = (int) __popcll(want_a) >= park_at || (~(idle2 | want_a)) == 0ull;
+#ifdef RT_FUSED_PUBLISH_WAVE
         bool last_of_tile = false; // FUSED: the lane's ray ends in this iteration and was the last one of its tile
+#endif
 #ifdef RT_WAVETIMES
         wt_a_runs += (do_a && want_a != 0ull) ? 1u : 0u;
         wt_b_runs += __ballot(st == ST_XSETUP) != 0ull ? 1u : 0u; // (lanes that arrive from [A2] in this iteration not counted)
@@ -1074,10 +1085,25 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 tot_skip += (fl & F_SKIP) ? 1u : 0u;
                 tot_rays++;
                 st = ST_IDLE;
+#ifdef RT_FUSED_PUBLISH_WAVE
                 if (FUSED) // one ray of the lane's tile less; the lane that takes the counter to zero has finished the tile
                     last_of_tile = __hip_atomic_fetch_add(&done.rem[cslot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 1u;
+#else
+                // One ray of the lane's tile less; the lane that takes the counter to zero has finished the tile and
+                // publishes it on the spot: every record of the tile was stored by THIS wave (the other rays retired in
+                // earlier iterations or in this very block), so once the wave's stores have landed the tile may be read.
+                // (Round 4 collected those lanes with a ballot after the block -- in every iteration, for an event that
+                // happens once in ~35: the loop head pays for every instruction, profiles/r05_express_cost.txt.)
+                if (FUSED) {
+                    if (__hip_atomic_fetch_add(&done.rem[cslot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 1u) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        tile_publish(done, ridx >> 6);
+                    }
+                }
+#endif
             }
         }
+#ifdef RT_FUSED_PUBLISH_WAVE
         if (FUSED) {
             unsigned long long lm = __ballot(last_of_tile);
             if (lm != 0ull) {
@@ -1110,6 +1136,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 } while (lm != 0ull);
             }
         }
+#endif
         RT_MARK(3); // DONE
         // ------------------------------------------------------------ [B] cross-cell setup (Helper.h:328-342)
         if (st == ST_XSETUP) {
