@@ -660,10 +660,11 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
         tb_iters++;
 #endif
         // ------------------------------------------------------------ refill
-        const unsigned long long idle = __ballot(st == ST_IDLE);
+        // (one ballot per iteration: the lane masks of the loop head come from `idle2`, which is taken again only when
+        // a refill has changed the states; a wave all of whose lanes are idle with nothing left to fetch leaves below)
+        unsigned long long idle2      = __ballot(st == ST_IDLE);
+        const unsigned long long idle = idle2;
         const int n_idle              = (int) __popcll(idle);
-        if (n_idle == WAVE && !more)
-            break;
 #if defined(RT_EXPRESS) || defined(RT_WAVETIMES)
         wave_iter++;
 #endif
@@ -858,10 +859,10 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 born      = wave_iter;
 #endif
             }
+            idle2 = __ballot(st == ST_IDLE);
         }
         // (at this point every lane is idle, waits for [A], or is in [B] / [C]: the three lane masks the loop
         // head needs follow from two ballots)
-        const unsigned long long idle2 = __ballot(st == ST_IDLE);
         if (idle2 == ~0ull) {
             if (!more)
                 break;
