@@ -1,4 +1,3 @@
-L=raytrace-miniapp_amd/csrc
-timeout -k 10 400 python -m pytest tests/test_gpu_fused.py tests/test_gpu_parity.py tests/test_gpu_edges.py -m gpu -x -q 2>&1 | tail -2
-timeout -k 10 500 python tools/exp.py --cases ase,small,shard8,seed $L/librt_hip.so $L/librt_hip_prev.so 2>&1
-timeout -k 10 500 python tools/exp.py --cases ase,small,shard8,seed $L/librt_hip_prev.so $L/librt_hip.so 2>&1
+python tools/shard_scaling.py > gpurun_out/r5_shard_scaling2.txt 2>&1
+python tools/fused_times.py > gpurun_out/r5_fused_times2.txt 2>&1
+python tools/exp.py --check --cases ase,seed > gpurun_out/r5_record_check2.txt 2>&1
