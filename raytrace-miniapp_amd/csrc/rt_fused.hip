@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(1024) rt_fused_kernel(const FusedKArg A)
     // against 2.65 ms, 8-rank shard 0.537 / 0.536 against 0.534; profiles/r04_prio_ab.txt)
     march_load_tables<true>(A.P, lds_raw);
     if (!consumer)
-        march_wave<true, BOUNDED, true>(A.P, lds_raw, list);
+        march_wave<true, BOUNDED, true, EMIS ? 1 : 0>(A.P, lds_raw, list); // (emission runs are backward runs: rt_launch.hip asks for it)
 
     // ---- phase 2: this wave's rays have run out; frequency pass on the work-group's finished tiles ----
     const int lane = lane_id();

@@ -325,7 +325,7 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     // 3.33 ms with four such waves, twice the rays 5.97 against 5.93 ms -- a wash, because what the one launch buys is the
     // idle end of the march, which is a fifth of a 0.5 ms launch and a hundredth of a 6 ms one, and what it costs is five
     // of sixteen waves marching less.  Two kernels stay the rule for this mode; RT_HIP_FUSED_SEED=1 takes the one launch.)
-    const bool fused_emis = p->P.use_emis && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32;
+    const bool fused_emis = p->P.use_emis && p->P.method == 1 && p->P.own_cells && p->P.rays.nga * p->P.rays.ngb >= 32;
     const bool fused_gain = !p->P.use_emis && p->P.rays.list == nullptr && env_unsigned("RT_HIP_FUSED_SEED", 0, 0, 1) == 1;
     const bool fused_cand = lds_tab && n_launch == 1 && p->n_rays > 0 && !p->path_on && !p->probe_on && p->P.debug == 0 &&
                             (fused_emis || fused_gain) && !p->P.exclusive && p->P.safe == 0 &&
@@ -352,8 +352,15 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     const bool force_ieee = getenv("RT_HIP_MARCH_IEEE") != nullptr;
     const bool bounded = p->tables_bounded && p->P.c_h3 >= 1e-8f && !force_ieee;
     using march_fn = void (*)(const rt::DevParams);
-    const march_fn kernel = lds_tab ? (bounded ? rt::rt_march_kernel<true, true> : rt::rt_march_kernel<true, false>)
-                                    : (bounded ? rt::rt_march_kernel<false, true> : rt::rt_march_kernel<false, false>);
+    // (the instance with method and emission switch fixed at compile time for the emission / backward pair, rt_march.hip
+    // MODE: the one-launch run -2.1 % with it.  The gain-only / forward pair was built the same way and came out 9 %
+    // SLOWER, 2.08 against 1.90 ms on seed_small -- same source, another register allocation: it keeps the run-time
+    // switches; profiles/r05_loop_head.txt)
+    const int mode = (p->P.use_emis && p->P.method == 1) ? 1 : 0;
+    const march_fn kernel =
+        lds_tab ? (bounded ? (mode == 1 ? rt::rt_march_kernel<true, true, 1> : rt::rt_march_kernel<true, true, 0>)
+                           : (mode == 1 ? rt::rt_march_kernel<true, false, 1> : rt::rt_march_kernel<true, false, 0>))
+                : (bounded ? rt::rt_march_kernel<false, true, 0> : rt::rt_march_kernel<false, false, 0>);
     if (lds_tab) {
         const int rc = allow_lds(reinterpret_cast<const void *>(kernel), p->device, mlds, p->lds_limit);
         if (rc != RT_OK)

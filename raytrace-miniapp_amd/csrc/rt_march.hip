@@ -528,15 +528,19 @@ template <bool LDS_TAB> __device__ __forceinline__ void march_load_tables(const 
     }
 }
 
-template <bool LDS_TAB, bool BOUNDED, bool FUSED>
+// MODE fixes the two run-time switches of the march at compile time where the host knows them (1: emission, backward
+// method -- every ASE run; 2: gain only, forward method -- every seeded run of create_image; 0: as DevParams says): as
+// run-time booleans they live in SGPR pairs that the register allocator spills into VGPR lanes and reads back
+// (v_readlane + wait states) in the cell set-up and the retirement block, i.e. in almost every iteration.
+template <bool LDS_TAB, bool BOUNDED, bool FUSED, int MODE = 0>
 __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *lds_raw, const TileList done)
 {
     const int lane        = lane_id();
     const int L           = P.L;
     const int S           = L * RT_N_SUB;
     const unsigned n_rays = P.ray_end; // this launch marches rays [P.ray_begin, P.ray_end)
-    const bool backward   = P.method == 1;
-    const bool use_emis   = P.use_emis != 0;
+    const bool backward   = MODE == 1 ? true : (MODE == 2 ? false : P.method == 1);
+    const bool use_emis   = MODE == 1 ? true : (MODE == 2 ? false : P.use_emis != 0);
     const unsigned CH     = P.chunk;
 #ifndef RT_REFILL
 #define RT_REFILL 8
@@ -1328,12 +1332,12 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     }
 }
 
-template <bool LDS_TAB, bool BOUNDED>
+template <bool LDS_TAB, bool BOUNDED, int MODE = 0>
 __global__ void __launch_bounds__(LDS_TAB ? 1024 : 256) rt_march_kernel(const DevParams P)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     march_load_tables<LDS_TAB>(P, lds_raw);
-    march_wave<LDS_TAB, BOUNDED, false>(P, lds_raw, TileList{ nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, 0u });
+    march_wave<LDS_TAB, BOUNDED, false, MODE>(P, lds_raw, TileList{ nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0u, 0u, 0u });
 }
 
 } // namespace rt

@@ -1,3 +1,3 @@
-python tools/shard_scaling.py > gpurun_out/r5_shard_scaling2.txt 2>&1
-python tools/fused_times.py > gpurun_out/r5_fused_times2.txt 2>&1
-python tools/exp.py --check --cases ase,seed > gpurun_out/r5_record_check2.txt 2>&1
+L=raytrace-miniapp_amd/csrc
+timeout -k 10 500 python tools/exp.py --cases ase,seed,small $L/librt_hip.so $L/librt_hip_prev.so 2>&1
+RT_HIP_FUSED=2 timeout -k 10 500 python tools/exp.py --cases ase,small $L/librt_hip.so $L/librt_hip_prev.so 2>&1
