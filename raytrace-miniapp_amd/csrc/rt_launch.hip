@@ -353,12 +353,14 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     const bool bounded = p->tables_bounded && p->P.c_h3 >= 1e-8f && !force_ieee;
     using march_fn = void (*)(const rt::DevParams);
     // (the instance with method and emission switch fixed at compile time for the emission / backward pair, rt_march.hip
-    // MODE: the one-launch run -2.1 % with it.  The gain-only / forward pair was built the same way and came out 9 %
-    // SLOWER, 2.08 against 1.90 ms on seed_small -- same source, another register allocation: it keeps the run-time
-    // switches; profiles/r05_loop_head.txt)
-    const int mode = (p->P.use_emis && p->P.method == 1) ? 1 : 0;
+    // MODE: the one-launch run -2.1 % with it; profiles/r05_loop_head.txt)
+    int mode = (p->P.use_emis && p->P.method == 1) ? 1 : 0;
+    // (gain-only, forward: only the method at compile time -- MODE 3, -0.7 %; with the emission switch fixed as well, or
+    // alone, the same source compiles to a march that is 5 - 9 % SLOWER: RT_HIP_MARCH_MODE = 2 / 4 / 0 to see it)
+    if (!p->P.use_emis && p->P.method == 2)
+        mode = (int) env_unsigned("RT_HIP_MARCH_MODE", 3, 0, 4);
     const march_fn kernel =
-        lds_tab ? (bounded ? (mode == 1 ? rt::rt_march_kernel<true, true, 1> : rt::rt_march_kernel<true, true, 0>)
+        lds_tab ? (bounded ? (mode == 1 ? rt::rt_march_kernel<true, true, 1> : mode == 2 ? rt::rt_march_kernel<true, true, 2> : mode == 3 ? rt::rt_march_kernel<true, true, 3> : mode == 4 ? rt::rt_march_kernel<true, true, 4> : rt::rt_march_kernel<true, true, 0>)
                            : (mode == 1 ? rt::rt_march_kernel<true, false, 1> : rt::rt_march_kernel<true, false, 0>))
                 : (bounded ? rt::rt_march_kernel<false, true, 0> : rt::rt_march_kernel<false, false, 0>);
     if (lds_tab) {

@@ -539,8 +539,9 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     const int L           = P.L;
     const int S           = L * RT_N_SUB;
     const unsigned n_rays = P.ray_end; // this launch marches rays [P.ray_begin, P.ray_end)
-    const bool backward   = MODE == 1 ? true : (MODE == 2 ? false : P.method == 1);
-    const bool use_emis   = MODE == 1 ? true : (MODE == 2 ? false : P.use_emis != 0);
+    // (MODE 3 / 4: only one of the two fixed, for the gain-only / forward pair -- experiments, see rt_launch.hip)
+    const bool backward   = MODE == 1 ? true : ((MODE == 2 || MODE == 3) ? false : P.method == 1);
+    const bool use_emis   = MODE == 1 ? true : ((MODE == 2 || MODE == 4) ? false : P.use_emis != 0);
     const unsigned CH     = P.chunk;
 #ifndef RT_REFILL
 #define RT_REFILL 8
