@@ -276,3 +276,28 @@ def test_seeded_mode_as_one_launch(hip, seed_small, seed_ref, monkeypatch):
     part = run_grid(hip, seed_small, True, count=64 * 3000 + 5)
     monkeypatch.delenv("RT_HIP_FUSED_SEED")
     same_images(part, run_grid(hip, seed_small, True, count=64 * 3000 + 5), tol=1e-12)
+
+
+@pytest.mark.parametrize("env", [{"RT_HIP_LATE2_X10": "0"}, {"RT_HIP_LATE2_X10": "400", "RT_HIP_LATE_WAVES": "1"},
+                                 {"RT_HIP_LATE2_X10": "60", "RT_HIP_LATE_CAP": "100", "RT_HIP_MARCH_THREADS": "256"},
+                                 {"RT_HIP_MARCH_MODE": "0"}, {"RT_HIP_MARCH_MODE": "2"}])
+def test_late_zone_and_compile_time_mode_of_the_march_kernel_leave_the_records_alone(hip, oracle, seed_small, ase_small, env, monkeypatch):
+    """The march as a kernel of its own (seeded mode; emission with RT_HIP_FUSED=2): the late zone of its ray list
+    (RT_HIP_LATE2_X10 / RT_HIP_LATE_WAVES / RT_HIP_LATE_CAP) and the instance with the method fixed at compile time
+    (RT_HIP_MARCH_MODE) hand every ray out exactly once and march it as ever: records bit-identical to the oracle's."""
+    import numpy as np
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("RT_HIP_FUSED", "2")
+    for p, n in ((seed_small, 64 * 2900 + 11), (ase_small, 64 * 1300 + 5)):
+        rays = p.build_rays(np.arange(n, dtype=np.int64))
+        with hip.Plan(p) as plan:
+            plan.set_ray_grid(count=n).enable_probe().run()
+            out = plan.fetch()
+            pr = plan.fetch_probe()
+            assert not plan.last_fused()
+        assert out["stats"]["n_rays"] == n
+        ref = oracle.probe(p, rays, want_Iv=False)
+        for key in ("gvl", "evl"):
+            assert np.array_equal(pr[key].view(np.uint32), ref[key].view(np.uint32)), key
+        assert np.array_equal(pr["ivl"], ref["ivl"]) and np.array_equal(pr["steps"], ref["steps"])
