@@ -354,10 +354,10 @@ int plan_launch_run(rt_hip_plan *p, hipStream_t stream)
     using march_fn = void (*)(const rt::DevParams);
     // (the instance with method and emission switch fixed at compile time for the emission / backward pair, rt_march.hip
     // MODE: the one-launch run -2.1 % with it; profiles/r05_loop_head.txt)
-    int mode = (p->P.use_emis && p->P.method == 1) ? 1 : 0;
+    int mode = (p->P.use_emis && p->P.method == 1 && !p->path_on) ? 1 : 0;
     // (gain-only, forward: only the method at compile time -- MODE 3, -0.7 %; with the emission switch fixed as well, or
     // alone, the same source compiles to a march that is 5 - 9 % SLOWER: RT_HIP_MARCH_MODE = 2 / 4 / 0 to see it)
-    if (!p->P.use_emis && p->P.method == 2)
+    if (!p->P.use_emis && p->P.method == 2 && !p->path_on)
         mode = (int) env_unsigned("RT_HIP_MARCH_MODE", 3, 0, 4);
     const march_fn kernel =
         lds_tab ? (bounded ? (mode == 1 ? rt::rt_march_kernel<true, true, 1> : mode == 2 ? rt::rt_march_kernel<true, true, 2> : mode == 3 ? rt::rt_march_kernel<true, true, 3> : mode == 4 ? rt::rt_march_kernel<true, true, 4> : rt::rt_march_kernel<true, true, 0>)

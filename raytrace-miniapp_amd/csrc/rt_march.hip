@@ -542,6 +542,8 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
     // (MODE 3 / 4: only one of the two fixed, for the gain-only / forward pair -- experiments, see rt_launch.hip)
     const bool backward   = MODE == 1 ? true : ((MODE == 2 || MODE == 3) ? false : P.method == 1);
     const bool use_emis   = MODE == 1 ? true : ((MODE == 2 || MODE == 4) ? false : P.use_emis != 0);
+    // (the path tracer is a debugging run: it takes the generic instance, the others carry none of its code)
+    const bool path_on    = MODE == 0 ? P.path_on != 0 : false;
     const unsigned CH     = P.chunk;
 #ifndef RT_REFILL
 #define RT_REFILL 8
@@ -835,7 +837,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 const float dsum  = sx + sy + sz;
                 const bool wild   = ((px != px) | (py != py) | (dsum != dsum)) &
                                   !((px < G0.lo_x) | (px > G0.hi_x) | (py < G0.lo_y) | (py > G0.hi_y));
-                if (P.path_on) { // Helper.h:419-426
+                if (path_on) { // Helper.h:419-426
                     float *pp = P.path + (size_t) ridx * 3 * (size_t) (S + 1) + 3 * (size_t) (backward ? S : 0);
                     pp[0]     = px;
                     pp[1]     = py;
@@ -857,7 +859,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 sx        = wild ? 0.0f : sx;
                 sy        = wild ? 0.0f : sy;
                 sz        = wild ? 0.0f : sz;
-                any_bits  = 0;
+                any_bits  = P.no_skip; // (non-zero: this ray is never marked F_SKIP -- a lineshape table holds a NaN, see DevParams)
                 sub       = 0;
                 st        = ST_CELL;
 #ifdef RT_EXPRESS
@@ -917,7 +919,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
 #endif
                 recp += backward ? -(int) REC_SLOT_ROW : (int) REC_SLOT_ROW; // the same ray's next slot: one slot row on
                 any_bits |= (__float_as_uint(gacc) | __float_as_uint(eacc)) & 0x7fffffffu;
-                if (P.path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
+                if (path_on) { // Helper.h:505-511: every remaining sub-segment of an escaped ray's
                                  // segment records the same position, later segments stay zero
                     float *pp = P.path + (size_t) ridx * 3 * (size_t) (S + 1);
                     for (int zz = iz; zz < (escaped ? RT_N_SUB : iz + 1); zz++) {
@@ -1061,7 +1063,7 @@ __device__ __forceinline__ void march_wave(const DevParams &P, unsigned char *ld
                 unsigned fl = F_VALID;
                 if (escaped)
                     fl |= F_ESCAPED;
-                if (use_emis && any_bits == 0u && !P.no_skip)
+                if (use_emis && any_bits == 0u)
                     fl |= F_SKIP; // every frequency update is the identity: contributes exactly +0 (finite lineshape)
                 RecMeta m;
                 m.px          = px;
